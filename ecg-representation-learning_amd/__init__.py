@@ -1,0 +1,14 @@
+"""
+ecg_representation_learning_amd -- MI355X-native (gfx950) drop-in for the ECG-ViT train step of
+StefanHeng/ECG-Representation-Learning (`ecg_transformer.models`): same `EcgVitConfig` / `EcgVit.forward ->
+ModelOutput(loss, logits)` / train-step surface, executed by hand-written HIP kernels behind a C-ABI
+(`include/ecgvit_hip.h`, `csrc/`).  Importing the package never needs a GPU; running the model does, and
+fails loudly when the HIP library is absent (no CPU / eager fallback by design).
+"""
+from .check_args import ca, CheckArg
+from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT
+from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
+from . import hip
+
+__all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'get_train_args', 'lr_multiplier',
+           'HipTrainStep', 'clip_grad_norm_', 'hip']

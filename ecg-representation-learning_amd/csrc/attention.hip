@@ -1,0 +1,411 @@
+// Fused multi-head self-attention core for the bf16 path (dh = 64, N <= 256 tokens): scores never touch HBM.
+//
+// One workgroup owns one (record, head): its whole K/V (<= 256 x 64 bf16 = 32 KiB each) sits in LDS, so softmax
+// is single-pass (no online rescale) and the backward needs no atomics -- dQ, dK, dV of a head are all produced
+// inside its workgroup.
+//
+// forward  (4 waves, one 32-query block per wave per pass):
+//   S^T = K . Q^T  (key on the accumulator ROW, query on the LANE)  -> row max / sum are in-lane + one xor-32 shuffle
+//   O^T = V^T . P^T : the S^T accumulator, packed to bf16, is directly the B operand (k order = accumulator row order);
+//                     V^T fragments come from the row-major V image through ds_read_b64_tr_b16.
+// backward (one wave per 32-key tile; loop over 32-query blocks):
+//   S = Q K^T and dP = dO V^T with the KEY on the lane, so P and dS (bf16) are directly the B operands of
+//   dV^T += dO^T . P and dK^T += Q^T . dS (A operands = transposed reads of the dO / Q images);
+//   dS crosses LDS once ([key][query] image) for dQ = dS . K, computed as 16x16x32 tiles, one per wave.
+//
+// LDS image for every [row][64 x bf16] tile (128-B rows):  16-B chunk index ^= bitrev3((row>>1)&7)
+//   -> ds_read_b128 row reads (MFMA K-contiguous operand) hit 16 distinct slots per 16-lane group, and
+//   -> ds_read_b64_tr_b16 reads of 4 consecutive rows x 64 B land in the 4 different 64-B quarters of the bank row.
+#include "common.cuh"
+
+namespace {
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ int swz3(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x & 2) | (x >> 2);
+}
+__device__ __forceinline__ int img_off(int row, int byte) { return row * 128 + ((((byte >> 4) ^ swz3(row)) << 4) | (byte & 15)); }
+
+// stage `rows_pad` rows x 128 B from global (row stride `ld` elements, rows >= nvalid zero-filled) into an image
+template <int NT>
+__device__ __forceinline__ void stage_image(char *img, const bf16_t *__restrict__ g, int64_t ld, int nvalid, int rows_pad) {
+    for (int c = threadIdx.x; c < rows_pad * 8; c += NT) {
+        const int row = c >> 3, ch = c & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < nvalid) v = *reinterpret_cast<const u32x4 *>(g + (int64_t)row * ld + ch * 8);
+        *reinterpret_cast<u32x4 *>(img + img_off(row, ch * 16)) = v;
+    }
+}
+
+// A/B operand fragment of a 32x32x16 MFMA whose k runs along the image's 64 columns: X[row0 + (lane&31)][16*ks + 8*(lane>>5) + j]
+__device__ __forceinline__ bf16x8 row_frag(const char *img, int row0, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8 *>(img + img_off(row0 + (lane & 31), (ks * 16 + 8 * (lane >> 5)) * 2));
+}
+
+// fragment whose k runs along the image ROWS in the "accumulator order" of a 32x32 tile:
+//   element j of lane (r = lane&31, h = lane>>5)  =  X[row0 + 8*(j>>2) + 4h + (j&3)][col0 + r]
+// (two transposed reads of 4 rows x 16 columns per 16-lane group)
+__device__ __forceinline__ bf16x8 tr_frag32(const char *img, int row0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const int row = row0 + 4 * (g >> 1) + (i >> 2);
+    const int colb = (col0 + (g & 1) * 16 + (i & 3) * 4) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + img_off(row, colb)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + img_off(row + 8, colb)));
+    bf16x8 o;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+    return o;
+}
+
+// pack accumulator registers 8*ss .. 8*ss+7 (x optional multipliers) into the bf16 B-operand fragment
+__device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)x[8 * ss + j];
+    return o;
+}
+
+// =====================================================================================================
+// forward: online softmax over 32-key tiles (running max / sum per query, O rescaled when the max moves)
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
+                                                               float *__restrict__ lse, int N, int h, float scale,
+                                                               uint64_t seed, uint32_t thresh, float inv_keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nkt = (N + 31) >> 5, NK = nkt * 32;
+    char *Kimg = smem, *Vimg = smem + NK * 128;
+    const int bh = blockIdx.x, b = bh / h, hd = bh - b * h;
+    const int d = h * 64;
+    const int64_t d3 = 3 * (int64_t)d;
+    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
+    stage_image<256>(Kimg, base + d, d3, N, NK);
+    stage_image<256>(Vimg, base + 2 * d, d3, N, NK);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float c = scale * 1.44269504088896340736f;
+    for (int qb = wave; qb < nkt; qb += 4) {
+        const int q = qb * 32 + lr;
+        const int qc = q < N ? q : N - 1;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
+        const uint64_t rowidx = ((uint64_t)bh * N + (uint64_t)qc) * (uint64_t)N;
+
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kimg, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= N) s[r] = -INFINITY;
+                mx = fmaxf(mx, s[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
+            const float alpha = exp2f((m - mn) * c);       // m = -inf on the first tile -> 0
+            m = mn;
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f((s[r] - mn) * c);
+                s[r] = p;
+                ls += p;
+            }
+            l = l * alpha + ls;                             // per-half partial sums; halves are combined after the loop
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            if (thresh) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    s[r] *= dropout_mult(seed, rowidx + key, thresh, inv_keep);
+                }
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 pf = pack8(s, ss);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(Vimg, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt], 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 32, 64);
+        if (q < N) {
+            const float inv = 1.0f / l;
+            bf16_t *orow = out + ((int64_t)b * N + q) * d + hd * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
+                    *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * g4 + 4 * lh) = v;
+                }
+            if (lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
+        }
+    }
+}
+
+// =====================================================================================================
+// backward
+// =====================================================================================================
+template <int NKT>
+__global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
+                                                                 const bf16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                                 bf16_t *__restrict__ dqkv, int N, int h, float scale,
+                                                                 uint64_t seed, uint32_t thresh, float inv_keep) {
+    constexpr int NK = NKT * 32, NT = NKT * 64;
+    constexpr int IMG = NK * 128, DSB = NK * 64;
+    __shared__ __attribute__((aligned(16))) char smem[3 * IMG + 2 * DSB + 2 * NK * 4];
+    char *Qimg = smem, *dOimg = smem + IMG, *Kimg = smem + 2 * IMG, *dSimg = smem + 3 * IMG;
+    float *lse_s = reinterpret_cast<float *>(smem + 3 * IMG + 2 * DSB), *delta_s = lse_s + NK;
+
+    const int bh = blockIdx.x, b = bh / h, hd = bh - b * h;
+    const int d = h * 64;
+    const int64_t d3 = 3 * (int64_t)d;
+    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
+    const bf16_t *dobase = dout + (int64_t)b * N * d + hd * 64;
+    const bf16_t *obase = out + (int64_t)b * N * d + hd * 64;
+    stage_image<NT>(Qimg, base, d3, N, NK);
+    stage_image<NT>(Kimg, base + d, d3, N, NK);
+    stage_image<NT>(dOimg, dobase, d, N, NK);
+    {   // delta[q] = sum_dh dO[q][dh] * O[q][dh] ; 8 lanes per row, 16 B each
+        const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+        for (int r0 = 0; r0 < NK; r0 += NT / 8) {
+            const int r = r0 + row;
+            float acc = 0.f;
+            if (r < N) {
+                const Vec16<bf16_t> a = ld16(dobase + (int64_t)r * d + part * 8), o = ld16(obase + (int64_t)r * d + part * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += a.get(k) * o.get(k);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (part == 0) {
+                delta_s[r] = acc;
+                lse_s[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : 0.f;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int mykey = wave * 32 + lr;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 k4 = {0u, 0u, 0u, 0u}, v4 = {0u, 0u, 0u, 0u};
+        if (mykey < N) {
+            k4 = *reinterpret_cast<const u32x4 *>(base + d + (int64_t)mykey * d3 + ks * 16 + 8 * lh);
+            v4 = *reinterpret_cast<const u32x4 *>(base + 2 * d + (int64_t)mykey * d3 + ks * 16 + 8 * lh);
+        }
+        kf[ks] = __builtin_bit_cast(bf16x8, k4);
+        vf[ks] = __builtin_bit_cast(bf16x8, v4);
+    }
+    __syncthreads();
+
+    f32x16 dKt[2], dVt[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dKt[dt][r] = 0.f; dVt[dt][r] = 0.f; }
+    const float c = scale * 1.44269504088896340736f;
+    const int nqb = (N + 31) >> 5;
+
+    for (int qb = 0; qb < nqb; ++qb) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qimg, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOimg, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+        // rows of s/dp = queries qb*32 + (r&3) + 8*(r>>2) + 4*lh ; column = my key
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[qb * 32 + 8 * g4 + 4 * lh]);
+            const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_s[qb * 32 + 8 * g4 + 4 * lh]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * g4 + k;
+                float p = exp2f(s[r] * c - l4[k]);
+                float g = dp[r];
+                if (thresh) {
+                    const int q = qb * 32 + 8 * g4 + 4 * lh + k;
+                    const float mlt = dropout_mult(seed, ((uint64_t)bh * N + (uint64_t)(q < N ? q : N - 1)) * (uint64_t)N + mykey, thresh, inv_keep);
+                    g *= mlt;
+                    s[r] = p * mlt;  // dropped probabilities feed dV
+                } else {
+                    s[r] = p;
+                }
+                dp[r] = p * (g - d4[k]) * scale;  // dS, in place
+            }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const bf16x8 pf = pack8(s, ss), dsf = pack8(dp, ss);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dVt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(dOimg, qb * 32 + 16 * ss, dt * 32, lane), pf, dVt[dt], 0, 0, 0);
+                dKt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(Qimg, qb * 32 + 16 * ss, dt * 32, lane), dsf, dKt[dt], 0, 0, 0);
+            }
+        }
+        // dS^T image [key][32 queries] (64-B rows; 32-B halves swapped on keys with bit 3 set)
+        char *dsb = dSimg + (qb & 1) * DSB;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (bf16_t)dp[4 * g4 + k];
+            const int qbyte = (8 * g4 + 4 * lh) * 2;
+            *reinterpret_cast<bf16x4 *>(dsb + mykey * 64 + (qbyte ^ (((mykey >> 3) & 1) << 5))) = v;
+        }
+        __syncthreads();
+        // dQ[32 x 64] = dS[32 x NK] . K[NK x 64] as 8 tiles of 16x16 (qt = tile&1, dhc = tile>>1)
+        for (int tile = wave; tile < 8; tile += NKT) {
+            const int qt = tile & 1, dhc = tile >> 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int g = lane >> 4, i = lane & 15;
+#pragma unroll
+            for (int st = 0; st < NKT; ++st) {
+                const int key = st * 32 + 8 * g + (i >> 2);
+                const int qb2 = (qt * 16 + (i & 3) * 4) * 2;
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + key * 64 + (qb2 ^ (((key >> 3) & 1) << 5))));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + (key + 4) * 64 + (qb2 ^ ((((key + 4) >> 3) & 1) << 5))));
+                const int dhb = (dhc * 16 + (i & 3) * 4) * 2;
+                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + img_off(key, dhb)));
+                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + img_off(key + 4, dhb)));
+                bf16x8 a, bb;
+                a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+                bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3]; bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3];
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+            }
+            const int dh = dhc * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qb * 32 + qt * 16 + g * 4 + r;
+                if (q < N) dqkv[((int64_t)b * N + q) * d3 + hd * 64 + dh] = (bf16_t)acc[r];
+            }
+        }
+    }
+    if (mykey < N) {
+        bf16_t *dk = dqkv + ((int64_t)b * N + mykey) * d3 + d + hd * 64, *dv = dk + d;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 a, v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a[k] = (bf16_t)dKt[dt][4 * g4 + k]; v[k] = (bf16_t)dVt[dt][4 * g4 + k]; }
+                *reinterpret_cast<bf16x4 *>(dk + dt * 32 + 8 * g4 + 4 * lh) = a;
+                *reinterpret_cast<bf16x4 *>(dv + dt * 32 + 8 * g4 + 4 * lh) = v;
+            }
+    }
+}
+
+// probe: exact-integer dump of what each lane receives from the fragment helpers (tests pin the layouts with it)
+__global__ __launch_bounds__(64) void probe_kernel(float *out) {
+    __shared__ __attribute__((aligned(16))) char img[64 * 128];
+    const int lane = threadIdx.x;
+    // image X[row][col] = row * 64 + col  (exact in bf16 only up to 256, so use row*2 + col/32 style codes per probe)
+    for (int c = lane; c < 64 * 64; c += 64) {
+        const int row = c >> 6, col = c & 63;
+        *reinterpret_cast<bf16_t *>(img + img_off(row, col * 2)) = (bf16_t)(float)(row * 2 + (col >> 5));  // <= 127: exact
+    }
+    __syncthreads();
+    const bf16x8 rf = row_frag(img, 32, 1, lane);          // rows 32.., k-step 1 (cols 16..31 -> col>>5 = 0)
+    const bf16x8 tf = tr_frag32(img, 16, 32, lane);        // rows 16.., cols 32.. (col>>5 = 1)
+    for (int j = 0; j < 8; ++j) {
+        out[(0 * 64 + lane) * 16 + j] = (float)rf[j];
+        out[(1 * 64 + lane) * 16 + j] = (float)tf[j];
+    }
+    // second image pass: code = col (0..63) to pin the column each lane gets
+    __syncthreads();
+    for (int c = lane; c < 64 * 64; c += 64) {
+        const int row = c >> 6, col = c & 63;
+        *reinterpret_cast<bf16_t *>(img + img_off(row, col * 2)) = (bf16_t)(float)col;
+    }
+    __syncthreads();
+    const bf16x8 rf2 = row_frag(img, 32, 1, lane);
+    const bf16x8 tf2 = tr_frag32(img, 16, 32, lane);
+    for (int j = 0; j < 8; ++j) {
+        out[(0 * 64 + lane) * 16 + 8 + j] = (float)rf2[j];
+        out[(1 * 64 + lane) * 16 + 8 + j] = (float)tf2[j];
+    }
+    // MFMA C layout: A[i][k] = (k == 0) ? i : 0 ; B[k][j] = (k == 0) ? 1 : 0 (+ second product coding the column)
+    bf16x8 a, bcol, ones;
+    for (int j = 0; j < 8; ++j) { a[j] = (bf16_t)0.f; bcol[j] = (bf16_t)0.f; ones[j] = (bf16_t)0.f; }
+    if ((lane >> 5) == 0) { a[0] = (bf16_t)(float)(lane & 31); ones[0] = (bf16_t)1.f; bcol[0] = (bf16_t)(float)(lane & 31); }
+    f32x16 z;
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    const f32x16 rowcode = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ones, z, 0, 0, 0);   // D[i][j] = i
+    const f32x16 colcode = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bcol, z, 0, 0, 0);  // D[i][j] = j
+    for (int r = 0; r < 16; ++r) {
+        out[(2 * 64 + lane) * 16 + r] = rowcode[r];
+        out[(3 * 64 + lane) * 16 + r] = colcode[r];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
+                         uint64_t seed, int dtype, void *stream) {
+    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) % 16) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    dim3 grid((unsigned)(B * h));
+    const size_t lds = (size_t)((N + 31) / 32) * 32 * 128 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                         int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 256 || B < 1 || h < 1) return ECGVIT_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) % 16) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    dim3 grid((unsigned)(B * h));
+    if (N <= 128)
+        hipLaunchKernelGGL(attn_bwd_bf16_kernel<4>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik);
+    else
+        hipLaunchKernelGGL(attn_bwd_bf16_kernel<8>, grid, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_probe_mfma_layout(float *out, void *stream) {
+    hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), out);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) ECG-ViT kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ecgvit_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+#define ECGVIT_CHECK_LAUNCH()                                    \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) return ECGVIT_ELAUNCH;            \
+    } while (0)
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- scalar conversions -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32 (RNE, NaN-safe)
+
+// ---- 16-byte vector access: VEC<T>::N elements per 16 B -------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v) *>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T *p, const Vec16<T> &r) {
+    *reinterpret_cast<decltype(r.v) *>(p) = r.v;
+}
+
+// ---- wave64 / block reductions ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over a block of NW waves; every thread gets the result. `red` = NW floats of LDS.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+
+// ---- exact-erf GELU (torch nn.GELU() default) ------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- counter-based dropout mask: keep(seed, element) is a pure function, recomputed in backward ----
+__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
+    uint64_t z = (idx + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ seed;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+// returns the multiplier: 0 or 1/(1-p)
+__device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+    return mix32(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+static inline uint32_t dropout_threshold(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// ---- epilogue parameters shared by the f32 and bf16 GEMMs -------------------------------------
+struct EpiParams {
+    int flags;
+    const float *bias;
+    const void *residual;
+    int64_t ldr;
+    void *aux;
+    int64_t ldaux;
+    float alpha;
+    uint64_t seed;
+    uint32_t drop_thresh;
+    float inv_keep;
+    int N;  // logical N for the dropout element index m*N+n
+};
+
+// apply everything except the final store / ACCUM; TO = element type of aux & residual
+template <typename TO> __device__ __forceinline__ float epilogue_value(float acc, int64_t m, int n, const EpiParams &e) {
+    float v = acc * e.alpha;
+    if (e.flags & ECGVIT_EPI_BIAS) v += e.bias[n];
+    if (e.flags & ECGVIT_EPI_GELU) {
+        reinterpret_cast<TO *>(e.aux)[m * e.ldaux + n] = from_f32<TO>(v);
+        // GELU of the value as STORED (so backward, which re-reads aux, sees the same pre-activation)
+        v = gelu_erf(to_f32<TO>(from_f32<TO>(v)));
+    }
+    if (e.flags & ECGVIT_EPI_DROPOUT) v *= dropout_mult(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep);
+    if (e.flags & ECGVIT_EPI_GELU_BWD) v *= gelu_erf_grad(to_f32<TO>(reinterpret_cast<const TO *>(e.aux)[m * e.ldaux + n]));
+    if (e.flags & ECGVIT_EPI_RESIDUAL) v += to_f32<TO>(reinterpret_cast<const TO *>(e.residual)[m * e.ldr + n]);
+    return v;
+}
+
+static inline EpiParams make_epi(const ecgvit_gemm_desc *d) {
+    EpiParams e;
+    e.flags = d->epilogue;
+    e.bias = d->bias;
+    e.residual = d->residual;
+    e.ldr = d->ldr;
+    e.aux = d->aux;
+    e.ldaux = d->ldaux;
+    e.alpha = d->alpha;
+    e.seed = d->dropout_seed;
+    e.drop_thresh = dropout_threshold(d->dropout_p);
+    e.inv_keep = d->dropout_p > 0.f ? 1.0f / (1.0f - d->dropout_p) : 1.0f;
+    e.N = d->N;
+    return e;
+}
+
+// internal launchers (defined in gemm_f32.hip / gemm_bf16.hip)
+int ecgvit_gemm_f32_launch(const ecgvit_gemm_desc *d, hipStream_t s);
+int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s);

@@ -1,0 +1,459 @@
+// HBM-bound row / elementwise kernels of the ECG-ViT step: patch gather, CLS+pos, LayerNorm fwd/bwd,
+// column sums (bias grads), row softmax (f32 parity path).  All are templated on the activation type
+// (float = parity path, bf16 = throughput path), move 16 B per lane per access, reduce with wave64
+// shuffles (one row per wave), and keep statistics / parameter gradients in f32.
+#include "common.cuh"
+
+namespace {
+
+// =====================================================================================================
+// patch gather: out[(b*n+p)*ld + j*C + c] = x[b][c][p*P + j]      (integer indexing, bit-exact)
+// One block = PB consecutive patches of one record: C coalesced row segments -> LDS -> PB contiguous rows.
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restrict__ x, T *__restrict__ out, int C, int L,
+                                                           int P, int n, int PB, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][W+1]
+    const int b = blockIdx.y, p0 = blockIdx.x * PB;
+    const int np = min(PB, n - p0), W = np * P, WS = PB * P + 1;
+    const float *xb = x + (int64_t)b * C * L + (int64_t)p0 * P;
+    for (int idx = threadIdx.x; idx < C * W; idx += 256) {
+        const int c = idx / W, s = idx - c * W;
+        tile[c * WS + s] = xb[(int64_t)c * L + s];
+    }
+    __syncthreads();
+    const int CP = C * P;
+    T *ob = out + ((int64_t)b * n + p0) * ld;
+    for (int idx = threadIdx.x; idx < np * (int)ld; idx += 256) {
+        const int pp = idx / (int)ld, f = idx - pp * (int)ld;
+        float v = 0.f;
+        if (f < CP) {
+            const int j = f / C, c = f - j * C;
+            v = tile[c * WS + pp * P + j];
+        }
+        ob[(int64_t)pp * ld + f] = from_f32<T>(v);
+    }
+}
+
+// =====================================================================================================
+// CLS concat + positional add (+ embedding dropout)
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__ tok, const float *__restrict__ cls,
+                                                           const float *__restrict__ pos, T *__restrict__ X, int B, int n,
+                                                           int d, uint64_t seed, uint32_t thresh, float inv_keep) {
+    constexpr int VN = Vec16<T>::N;
+    const int N = n + 1, dv = d / VN;
+    const int64_t total = (int64_t)B * N * dv;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % dv);
+        const int64_t row = i / dv;
+        const int t = (int)(row % N);
+        const int64_t b = row / N;
+        const int c0 = cv * VN;
+        Vec16<T> o;
+        if (t == 0) {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) o.set(k, cls[c0 + k] + pos[c0 + k]);
+        } else {
+            const Vec16<T> v = ld16(tok + (b * n + (t - 1)) * (int64_t)d + c0);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) o.set(k, v.get(k) + pos[(int64_t)t * d + c0 + k]);
+        }
+        if (thresh) {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * dropout_mult(seed, (uint64_t)(row * d + c0 + k), thresh, inv_keep));
+        }
+        st16(X + row * d + c0, o);
+    }
+}
+
+// dtok copy + dpos/dcls reductions over the batch. One thread per (token t, 16-B column chunk), loop over b.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const T *__restrict__ dX, T *__restrict__ dtok, float *__restrict__ dcls,
+                                                        float *__restrict__ dpos, int B, int n, int d, uint64_t seed,
+                                                        uint32_t thresh, float inv_keep) {
+    constexpr int VN = Vec16<T>::N;
+    const int N = n + 1, dv = d / VN;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * dv) return;
+    const int t = i / dv, c0 = (i - t * dv) * VN;
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const int64_t row = (int64_t)b * N + t;
+        Vec16<T> v = ld16(dX + row * d + c0);
+        if (thresh) {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint64_t)(row * d + c0 + k), thresh, inv_keep));
+        }
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
+        if (t > 0) st16(dtok + ((int64_t)b * n + (t - 1)) * d + c0, v);
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        dpos[(int64_t)t * d + c0 + k] = acc[k];
+        if (t == 0) dcls[c0 + k] = acc[k];
+    }
+}
+
+// =====================================================================================================
+// LayerNorm: one row per wave, row cached in registers (d <= 64 * VN * MAXV)
+// =====================================================================================================
+// MAXV = ceil(d / (64 * VN)) rounded up to a power of two, chosen at launch (d <= 2048)
+
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, T *__restrict__ y,
+                                                            float *__restrict__ mean, float *__restrict__ rstd, int64_t rows,
+                                                            int d, float eps) {
+    constexpr int VN = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * 4ll + (threadIdx.x >> 6), nw = gridDim.x * 4ll;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t r = wave0; r < rows; r += nw) {
+        const T *xr = x + r * d;
+        Vec16<T> v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VN;
+            if (c < d) {
+                v[i] = ld16(xr + c);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) s += v[i].get(k);
+            }
+        }
+        const float mu = wave_sum(s) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VN;
+            if (c < d) {
+#pragma unroll
+                for (int k = 0; k < VN; ++k) { const float t = v[i].get(k) - mu; q += t * t; }
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * inv_d + eps);
+        T *yr = y + r * d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VN;
+            if (c < d) {
+                Vec16<T> o;
+#pragma unroll
+                for (int k = 0; k < VN; ++k) o.set(k, (v[i].get(k) - mu) * rs * gamma[c + k] + beta[c + k]);
+                st16(yr + c, o);
+            }
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; per-block partial dgamma/dbeta
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                                                            const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                            const float *__restrict__ rstd, const T *__restrict__ dres,
+                                                            T *__restrict__ dx, float *__restrict__ partial, int64_t rows, int d) {
+    constexpr int VN = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave0 = blockIdx.x * 4ll + w, nw = gridDim.x * 4ll;
+    const float inv_d = 1.0f / (float)d;
+    float ag[MAXV][VN], ab[MAXV][VN], gm[MAXV][VN];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * VN;
+#pragma unroll
+        for (int k = 0; k < VN; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; gm[i][k] = c < d ? gamma[c + k] : 0.f; }
+    }
+    for (int64_t r = wave0; r < rows; r += nw) {
+        const float mu = mean[r], rs = rstd[r];
+        Vec16<T> vd[MAXV];
+        float xh[MAXV][VN];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VN;
+            if (c < d) {
+                vd[i] = ld16(dy + r * d + c);
+                const Vec16<T> vx = ld16(x + r * d + c);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    xh[i][k] = (vx.get(k) - mu) * rs;
+                    const float g = vd[i].get(k) * gm[i][k];
+                    s1 += g;
+                    s2 += g * xh[i][k];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * VN;
+            if (c < d) {
+                Vec16<T> o;
+                Vec16<T> res;
+                if (dres) res = ld16(dres + r * d + c);
+#pragma unroll
+                for (int k = 0; k < VN; ++k) {
+                    const float dyv = vd[i].get(k);
+                    float v = rs * (dyv * gm[i][k] - c1 - xh[i][k] * c2);
+                    if (dres) v += res.get(k);
+                    o.set(k, v);
+                    ag[i][k] += dyv * xh[i][k];
+                    ab[i][k] += dyv;
+                }
+                st16(dx + r * d + c, o);
+            }
+        }
+    }
+    // block reduction of the 4 waves' column sums, then one partial row per block: partial[block][2][d]
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * VN;
+        if (c < d) {
+#pragma unroll
+            for (int k = 0; k < VN; ++k) { red[(w * 2 + 0) * d + c + k] = ag[i][k]; red[(w * 2 + 1) * d + c + k] = ab[i][k]; }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) s += red[ww * 2 * d + c];
+        partial[(int64_t)blockIdx.x * 2 * d + c] = s;
+    }
+}
+
+// out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
+                                                              float *__restrict__ out0, float *__restrict__ out1, int split) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * width + c];
+    if (c < split) out0[c] = s;
+    else out1[c - split] = s;
+}
+
+// =====================================================================================================
+// column sums: out[n] = sum_m in[m][n]
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ in, int64_t ld, float *__restrict__ partial, int64_t M,
+                                                     int N, int rows_per_block) {
+    constexpr int VN = Vec16<T>::N;
+    __shared__ float red[4][64 * VN];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * VN;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    if (c < N) {
+        for (int64_t r = r0 + w; r < r1; r += 4) {
+            const Vec16<T> v = ld16(in + r * ld + c);
+#pragma unroll
+            for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) red[w][lane * VN + k] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * VN; i += 256) {
+        const int cc = blockIdx.x * 64 * VN + i;
+        if (cc < N) partial[(int64_t)blockIdx.y * N + cc] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+
+// =====================================================================================================
+// f32 parity-path softmax over materialised scores: one row per wave
+// =====================================================================================================
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float *__restrict__ S, int64_t rows, int N, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * 4ll + (threadIdx.x >> 6), nw = gridDim.x * 4ll;
+    for (int64_t r = wave0; r < rows; r += nw) {
+        float *s = S + r * ld;
+        float m = -INFINITY;
+        for (int c = lane; c < N; c += 64) m = fmaxf(m, s[c]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int c = lane; c < N; c += 64) sum += expf(s[c] - m);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int c = lane; c < N; c += 64) s[c] = expf(s[c] - m) * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float *__restrict__ P, float *__restrict__ dP, int64_t rows,
+                                                               int N, int64_t ld, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * 4ll + (threadIdx.x >> 6), nw = gridDim.x * 4ll;
+    for (int64_t r = wave0; r < rows; r += nw) {
+        const float *p = P + r * ld;
+        float *g = dP + r * ld;
+        float dot = 0.f;
+        for (int c = lane; c < N; c += 64) dot += p[c] * g[c];
+        dot = wave_sum(dot);
+        for (int c = lane; c < N; c += 64) g[c] = p[c] * (g[c] - dot) * scale;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const T *__restrict__ in, T *__restrict__ out, int64_t count,
+                                                            uint64_t seed, uint32_t thresh, float inv_keep) {
+    constexpr int VN = Vec16<T>::N;
+    const int64_t nv = count / VN;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> v = ld16(in + i * VN);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint64_t)(i * VN + k), thresh, inv_keep));
+        st16(out + i * VN, v);
+    }
+}
+
+inline int grid_for_rows(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 2048); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ecgvit_patch_gather(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream) {
+    if (B <= 0 || C <= 0 || P <= 0 || L <= 0 || L % P != 0 || ld < (int64_t)C * P) return ECGVIT_EINVAL;
+    const int n = L / P;
+    int PB = std::max(1, 256 / P);
+    while (PB > 1 && (size_t)C * (PB * P + 1) * 4 > 48 * 1024) PB >>= 1;
+    const size_t lds = (size_t)C * (PB * P + 1) * 4;
+    if (lds > 64 * 1024) return ECGVIT_EINVAL;
+    dim3 grid((n + PB - 1) / PB, B);
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(patch_gather_kernel<float>, grid, dim3(256), lds, as_stream(stream), x, (float *)patches, C, L, P, n, PB, ld);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, grid, dim3(256), lds, as_stream(stream), x, (bf16_t *)patches, C, L, P, n, PB, ld);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, void *X, int B, int n, int d, float dropout_p,
+                        uint64_t seed, int dtype, void *stream) {
+    if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const int64_t total = (int64_t)B * (n + 1) * d / (dtype == ECGVIT_F32 ? 4 : 8);
+    const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(embed_finish_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)tok, cls, pos, (float *)X, B, n, d, seed, th, ik);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(embed_finish_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)tok, cls, pos, (bf16_t *)X, B, n, d, seed, th, ik);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B, int n, int d, float dropout_p, uint64_t seed,
+                     int dtype, void *stream) {
+    if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const int work = (n + 1) * (d / (dtype == ECGVIT_F32 ? 4 : 8));
+    const int grid = (work + 255) / 256;
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)dX, (float *)dtok, dcls, dpos, B, n, d, seed, th, ik);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)dX, (bf16_t *)dtok, dcls, dpos, B, n, d, seed, th, ik);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, int64_t rows,
+                         int d, float eps, int dtype, void *stream) {
+    if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048) return ECGVIT_EINVAL;
+    const int grid = grid_for_rows(rows);
+    if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
+    const int nv = (d + (dtype == ECGVIT_F32 ? 256 : 512) - 1) / (dtype == ECGVIT_F32 ? 256 : 512);
+#define LN_FWD(T, MV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, MV>), dim3(grid), dim3(256), 0, as_stream(stream), (const T *)x, gamma, beta, (T *)y, mean, rstd, rows, d, eps)
+    if (dtype == ECGVIT_F32) { if (nv <= 1) LN_FWD(float, 1); else if (nv <= 2) LN_FWD(float, 2); else if (nv <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
+    else { if (nv <= 1) LN_FWD(bf16_t, 1); else if (nv <= 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
+#undef LN_FWD
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 512); }
+
+int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln_bwd_grid(rows) * 2 * d * 4; }
+
+int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                         void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, int dtype, void *stream) {
+    if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048 || !partial) return ECGVIT_EINVAL;
+    const int grid = ln_bwd_grid(rows);
+    const size_t lds = (size_t)4 * 2 * d * 4;
+    if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
+    const int nv = (d + (dtype == ECGVIT_F32 ? 256 : 512) - 1) / (dtype == ECGVIT_F32 ? 256 : 512);
+#define LN_BWD(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(grid), dim3(256), lds, as_stream(stream), (const T *)dy, (const T *)x, gamma, mean, rstd, (const T *)dres, (T *)dx, (float *)partial, rows, d)
+    if (dtype == ECGVIT_F32) { if (nv <= 1) LN_BWD(float, 1); else if (nv <= 2) LN_BWD(float, 2); else if (nv <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
+    else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
+#undef LN_BWD
+    ECGVIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, as_stream(stream), (const float *)partial, grid, 2 * d, dgamma, dbeta, d);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+static int colsum_row_blocks(int64_t M) { return (int)std::min<int64_t>((M + 255) / 256, 256); }
+
+int64_t ecgvit_colsum_workspace(int64_t M, int N) { return (int64_t)colsum_row_blocks(M) * N * 4; }
+
+int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t M, int N, int dtype, void *stream) {
+    if (M <= 0 || N <= 0 || N % 8 != 0 || ld % 8 != 0 || !partial) return ECGVIT_EINVAL;
+    const int rb = colsum_row_blocks(M);
+    const int rpb = (int)((M + rb - 1) / rb);
+    const int vn = dtype == ECGVIT_F32 ? 4 : 8;
+    dim3 grid((N + 64 * vn - 1) / (64 * vn), rb);
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float *)in, ld, (float *)partial, M, N, rpb);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)in, ld, (float *)partial, M, N, rpb);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_dropout_apply(const void *in, void *out, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    if (count <= 0 || count % 8 != 0) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const int grid = (int)std::min<int64_t>((count / 4 + 255) / 256, 4096);
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)in, (float *)out, count, seed, th, ik);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)in, (bf16_t *)out, count, seed, th, ik);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_softmax_rows(float *S, int64_t rows, int N, int64_t ld, void *stream) {
+    if (rows <= 0 || N <= 0 || ld < N) return ECGVIT_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, as_stream(stream), S, rows, N, ld);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_softmax_bwd_rows(const float *P, float *dP, int64_t rows, int N, int64_t ld, float scale, void *stream) {
+    if (rows <= 0 || N <= 0 || ld < N) return ECGVIT_EINVAL;
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(grid_for_rows(rows)), dim3(256), 0, as_stream(stream), P, dP, rows, N, ld, scale);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+}  // extern "C"

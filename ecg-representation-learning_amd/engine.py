@@ -1,0 +1,327 @@
+"""
+Host-side schedule of the ECG-ViT step over the C-ABI kernels (`include/ecgvit_hip.h`).
+
+This file holds NO arithmetic: it owns the HBM layout (flat f32 parameter / gradient / optimiser buffers,
+a bf16 shadow of the weights, per-layer activation slabs kept resident for the backward pass -- 288 GB of
+HBM3E makes recomputation pointless at these sizes) and issues the kernels in order on the current HIP
+stream.  What each launch replaces in the reference is cited at the call site
+(vit-pytorch 0.33.2 `ViT.forward` reached from `ecg_transformer/models/ecg_vit.py:141`).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+from .hip import lib, check, ptr, stream, GEMM_NT, GEMM_NN, GEMM_TN
+from .hip import EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_DROPOUT
+
+LN_EPS = 1e-5  # nn.LayerNorm default, used by vit_pytorch PreNorm / mlp_head
+
+
+def _align(n, a=8):
+    return (n + a - 1) // a * a
+
+
+class ParamLayout:
+    """name -> (offset, shape) inside one flat f32 buffer; every tensor starts on a 32-B boundary so the same
+    offsets address the bf16 shadow on 16-B boundaries (vector loads everywhere)."""
+
+    def __init__(self, named_shapes):
+        self.entries = OrderedDict()
+        off = 0
+        for name, shape in named_shapes:
+            n = 1
+            for s in shape:
+                n *= s
+            self.entries[name] = (off, tuple(shape), n)
+            off = _align(off + n)
+        self.total = off
+
+    def view(self, flat, name):
+        off, shape, n = self.entries[name]
+        return flat[off:off + n].view(shape)
+
+
+class VitEngine:
+    """Forward / backward of EcgVit for one activation dtype (torch.float32 = parity path, torch.bfloat16 =
+    throughput path). Caller provides the flat buffers; all activations are allocated here, once per batch size."""
+
+    def __init__(self, *, C, L, P, d, h, f, Ly, K, p_hidden, p_emb, dtype, layout: ParamLayout):
+        assert L % P == 0, 'Image dimensions must be divisible by the patch size.'  # vit_pytorch's own assertion text
+        self.C, self.L, self.P, self.d, self.h, self.f, self.Ly, self.K = C, L, P, d, h, f, Ly, K
+        self.n = L // P
+        self.N = self.n + 1
+        self.dh = d // h
+        self.CP = C * P
+        self.p_hidden, self.p_emb = float(p_hidden), float(p_emb)
+        self.dtype = dtype
+        self.layout = layout
+        self.scale = self.dh ** -0.5
+        if d % 8 or f % 8 or self.CP % 8 or self.dh % 8:
+            raise ValueError(f'HIP path needs hidden_size, intermediate_size, head dim and C*P to be multiples of 8 '
+                             f'(got d={d}, f={f}, dh={self.dh}, C*P={self.CP})')
+        if d > 2048:
+            raise ValueError('HIP LayerNorm kernels cover hidden_size <= 2048')
+        if h == 1:
+            raise NotImplementedError('heads == 1 (vit_pytorch drops to_out) is not covered by the HIP path')
+        if dtype == torch.bfloat16:
+            if self.dh != 64:
+                raise ValueError(f'bf16 fused attention needs head dim 64 (got {self.dh}); use dtype=torch.float32')
+            if self.N > 256:
+                raise ValueError(f'bf16 fused attention backward covers <= 256 tokens (got {self.N})')
+        self.B = None
+        self.act = None
+        self.P32 = self.G32 = self.W = None
+        self._ws = {}
+        self.saved = None
+
+    # ---------------------------------------------------------------- buffers
+    def bind(self, pflat, gflat, wlow=None):
+        """pflat/gflat: flat f32 params / grads. wlow: flat bf16 shadow of pflat (bf16 engine only)."""
+        lay = self.layout
+        self.P32 = {k: lay.view(pflat, k) for k in lay.entries}
+        self.G32 = {k: lay.view(gflat, k) for k in lay.entries}
+        if self.dtype == torch.bfloat16:
+            assert wlow is not None and wlow.dtype == torch.bfloat16
+            self.W = {k: lay.view(wlow, k) for k in lay.entries}
+        else:
+            self.W = self.P32
+        self.device = pflat.device
+
+    def _alloc(self, B):
+        if self.B == B and self.act is not None:
+            return
+        dev, T = self.device, self.dtype
+        M, Mp = B * self.N, B * self.n
+        d, f, h, N = self.d, self.f, self.h, self.N
+        e = lambda *s, dt=T: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        a = dict(patches=e(Mp, self.CP), tok=e(Mp, d), x0=e(M, d))
+        L = []
+        for _ in range(self.Ly):
+            l = dict(mean1=e(M, dt=torch.float32), rstd1=e(M, dt=torch.float32), xn1=e(M, d), qkv=e(M, 3 * d),
+                     attn=e(M, d), x1=e(M, d), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32),
+                     xn2=e(M, d), hpre=e(M, f), hact=e(M, f), x2=e(M, d))
+            if T == torch.float32:
+                l['probs'] = e(B * h * N * N)
+            else:
+                l['lse'] = e(B * h * N, dt=torch.float32)
+            L.append(l)
+        a['layers'] = L
+        a.update(logits=e(B, self.K, dt=torch.float32), xhat=e(B, d, dt=torch.float32), hrstd=e(B, dt=torch.float32),
+                 loss_elem=e(B, self.K, dt=torch.float32), loss_mean=e(1, dt=torch.float32),
+                 dlogits=e(B, self.K, dt=torch.float32))
+        # backward scratch (shared by all layers)
+        a.update(dxa=e(M, d), dxb=e(M, d), dxn=e(M, d), dqkv=e(M, 3 * d), dattn=e(M, d), dh=e(M, f), dtok=e(Mp, d),
+                 dxm=e(M, d))
+        if T == torch.float32:
+            a.update(pd=e(B * h * N * N), dp=e(B * h * N * N))
+        l = lib()
+        ws = max(l.ecgvit_layernorm_bwd_workspace(M, d), l.ecgvit_colsum_workspace(M, max(f, 3 * d)), 4096)
+        if T == torch.bfloat16:
+            for (mm, nn) in ((d, f), (f, d), (d, d), (3 * d, d), (d, self.CP)):
+                ws = max(ws, hip.gemm_workspace_bytes(GEMM_TN, T, mm, nn, M))
+        a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
+        self.act, self.B = a, B
+
+    # ---------------------------------------------------------------- small launch helpers
+    def _ln_fwd(self, x, g, b, y, mean, rstd, rows):
+        check(lib().ecgvit_layernorm_fwd(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, self.d, LN_EPS,
+                                         hip.code(self.dtype), stream()), 'layernorm_fwd')
+
+    def _ln_bwd(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows):
+        check(lib().ecgvit_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
+                                         ptr(self.act['ws']), rows, self.d, hip.code(self.dtype), stream()), 'layernorm_bwd')
+
+    def _colsum(self, x, ld, out, M, N):
+        check(lib().ecgvit_colsum(ptr(x), ld, ptr(out), ptr(self.act['ws']), M, N, hip.code(self.dtype), stream()), 'colsum')
+
+    def _drop_apply(self, src, dst, count, p, seed):
+        check(lib().ecgvit_dropout_apply(ptr(src), ptr(dst), count, p, seed, hip.code(self.dtype), stream()), 'dropout_apply')
+
+    def _wgrad(self, dY, X, name, Mout, Nin, rows):
+        """dW[Mout, Nin] = dY[rows, Mout]^T . X[rows, Nin]  -> f32 gradient view (overwritten)"""
+        hip.gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, x, labels=None, weight=None, training=True, seed=0, want_mean=True):
+        """x: (B, C, L) f32 contiguous device tensor. Returns (logits (B,K) f32, loss_elem (B,K) f32 | None, loss_mean (1,) | None)."""
+        B = x.shape[0]
+        assert x.shape[1] == self.C and x.shape[2] == self.L and x.dtype == torch.float32 and x.is_contiguous()
+        self._alloc(B)
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        d, f, h, dh, N, n = self.d, self.f, self.h, self.dh, self.N, self.n
+        M, Mp = B * N, B * n
+        ph = self.p_hidden if training else 0.0
+        pe = self.p_emb if training else 0.0
+        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight)
+        pre = 'vit.'
+        # a4: patch Rearrange (integer gather) + Linear(C*P, d)
+        check(l.ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, st), 'patch_gather')
+        hip.gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], Mp, d, self.CP, self.CP, self.CP, d,
+                 epilogue=EPI_BIAS, bias=self.P32[pre + 'to_patch_embedding.1.bias'])
+        # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout
+        check(l.ecgvit_embed_finish(ptr(a['tok']), ptr(self.P32[pre + 'cls_token']), ptr(self.P32[pre + 'pos_embedding']),
+                                    ptr(a['x0']), B, n, d, pe, seed + 1, T, st), 'embed_finish')
+        X = a['x0']
+        for i, L in enumerate(a['layers']):
+            lp = f'{pre}transformer.layers.{i}.'
+            s0 = seed + 100 * (i + 1)
+            # a6/a7: PreNorm(Attention)
+            self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M)
+            hip.gemm(GEMM_NT, L['xn1'], W[lp + '0.fn.to_qkv.weight'], L['qkv'], M, 3 * d, d, d, d, 3 * d)
+            if self.dtype == torch.bfloat16:
+                check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
+                                             T, st), 'attention_fwd')
+            else:
+                self._attn_fwd_f32(L, B, ph, s0 + 1)
+            epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
+            hip.gemm(GEMM_NT, L['attn'], W[lp + '0.fn.to_out.0.weight'], L['x1'], M, d, d, d, d, d, epilogue=epi,
+                     bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
+            # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
+            self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M)
+            epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0)
+            hip.gemm(GEMM_NT, L['xn2'], W[lp + '1.fn.net.0.weight'], L['hact'], M, f, d, d, d, f, epilogue=epi,
+                     bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
+            epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
+            hip.gemm(GEMM_NT, L['hact'], W[lp + '1.fn.net.3.weight'], L['x2'], M, d, f, f, f, d, epilogue=epi,
+                     bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
+            X = L['x2']
+        self.saved['xL'] = X
+        # a10: x[:, 0] -> LayerNorm -> Linear(d, K)
+        check(l.ecgvit_head_fwd(ptr(X), N, ptr(self.P32[pre + 'mlp_head.0.weight']), ptr(self.P32[pre + 'mlp_head.0.bias']),
+                                ptr(self.P32[pre + 'mlp_head.1.weight']), ptr(self.P32[pre + 'mlp_head.1.bias']),
+                                ptr(a['logits']), ptr(a['xhat']), ptr(a['hrstd']), B, d, self.K, LN_EPS, T, st), 'head_fwd')
+        if labels is None:
+            return a['logits'], None, None
+        # a11: BCEWithLogitsLoss
+        check(l.ecgvit_bce_fwd(ptr(a['logits']), ptr(labels), ptr(weight), ptr(a['loss_elem']),
+                               ptr(a['loss_mean']) if want_mean else None, B * self.K, st), 'bce_fwd')
+        return a['logits'], a['loss_elem'], (a['loss_mean'] if want_mean else None)
+
+    def _attn_fwd_f32(self, L, B, ph, seed):
+        """f32 parity path of Attention.forward: dots = q k^T * scale (batched exact-f32 MFMA GEMM), softmax, attn v."""
+        d, h, dh, N = self.d, self.h, self.dh, self.N
+        qkv, S = L['qkv'], L['probs']
+        sq = (N * 3 * d, dh)
+        hip.gemm(GEMM_NT, qkv, qkv, S, N, N, dh, 3 * d, 3 * d, N, alpha=self.scale, batch=(B, h), strideA=sq, strideB=sq,
+                 strideC=(h * N * N, N * N), b_off=d)
+        check(lib().ecgvit_softmax_rows(ptr(S), B * h * N, N, N, stream()), 'softmax_rows')
+        Pd = S
+        if ph > 0:
+            Pd = self.act['pd']
+            self._drop_apply_f32(S, Pd, B * h * N * N, ph, seed)
+        hip.gemm(GEMM_NN, Pd, qkv, L['attn'], N, dh, N, N, 3 * d, d, batch=(B, h), strideA=(h * N * N, N * N), strideB=sq,
+                 strideC=(N * d, dh), b_off=2 * d)
+
+    def _drop_apply_f32(self, src, dst, count, p, seed):
+        # element index = ((b*h + head)*N + q)*N + key: identical to the fused bf16 kernel's mask
+        cnt8 = count // 8 * 8
+        check(lib().ecgvit_dropout_apply(ptr(src), ptr(dst), cnt8, p, seed, hip.F32, stream()), 'dropout_apply')
+        if cnt8 != count:
+            raise ValueError('f32 attention dropout needs B*h*N*N to be a multiple of 8')
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, gscalar=None, gelem=None, gscale=1.0, glogits=None):
+        """Overwrites every gradient view in gflat. Upstream: `gscalar` (1,) for the mean loss, or `gelem` (B,K) for
+        reduction='none'; gscale folds the 1/(B*K) of the mean. `glogits` (B,K): extra upstream gradient on the logits."""
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        sv = self.saved
+        B, ph, pe, seed = sv['B'], sv['ph'], sv['pe'], sv['seed']
+        d, f, h, dh, N, n = self.d, self.f, self.h, self.dh, self.N, self.n
+        M, Mp = B * N, B * n
+        pre = 'vit.'
+        G = self.G32
+        if sv['labels'] is not None and (gscalar is not None or gelem is not None):
+            check(l.ecgvit_bce_bwd(ptr(a['logits']), ptr(sv['labels']), ptr(sv['weight']), ptr(gscalar), ptr(gelem), gscale,
+                                   ptr(a['dlogits']), B * self.K, st), 'bce_bwd')
+            dlog = a['dlogits']
+            if glogits is not None:
+                raise NotImplementedError('simultaneous loss and logits upstream gradients')
+        elif glogits is not None:
+            dlog = glogits
+        else:
+            raise ValueError('backward needs an upstream gradient')
+        dX = a['dxa']
+        check(l.ecgvit_head_bwd(ptr(dlog), ptr(a['xhat']), ptr(a['hrstd']), ptr(self.P32[pre + 'mlp_head.0.weight']),
+                                ptr(self.P32[pre + 'mlp_head.0.bias']), ptr(self.P32[pre + 'mlp_head.1.weight']),
+                                ptr(G[pre + 'mlp_head.1.weight']), ptr(G[pre + 'mlp_head.1.bias']),
+                                ptr(G[pre + 'mlp_head.0.weight']), ptr(G[pre + 'mlp_head.0.bias']), ptr(dX), N, B, d, self.K,
+                                T, st), 'head_bwd')
+        other = a['dxb']
+        for i in reversed(range(self.Ly)):
+            L = a['layers'][i]
+            lp = f'{pre}transformer.layers.{i}.'
+            s0 = seed + 100 * (i + 1)
+            Xin = a['x0'] if i == 0 else a['layers'][i - 1]['x2']
+            # ---- FeedForward backward: x2 = drop(hact W2^T + b2) + x1
+            dY = dX
+            if ph > 0:
+                self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 4)
+                dY = a['dxm']
+            self._colsum(dY, d, G[lp + '1.fn.net.3.bias'], M, d)
+            self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M)
+            epi = EPI_GELU_BWD | (EPI_DROPOUT if ph > 0 else 0)
+            hip.gemm(GEMM_NN, dY, W[lp + '1.fn.net.3.weight'], a['dh'], M, f, d, d, f, f, epilogue=epi, aux=L['hpre'], ldaux=f,
+                     dropout_p=ph, seed=s0 + 3)
+            self._colsum(a['dh'], f, G[lp + '1.fn.net.0.bias'], M, f)
+            self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
+            hip.gemm(GEMM_NN, a['dh'], W[lp + '1.fn.net.0.weight'], a['dxn'], M, d, f, f, d, d)
+            self._ln_bwd(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
+                         G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M)
+            dX, other = other, dX  # dX = d(x1)
+            # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
+            dY = dX
+            if ph > 0:
+                self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 2)
+                dY = a['dxm']
+            self._colsum(dY, d, G[lp + '0.fn.to_out.0.bias'], M, d)
+            self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
+            hip.gemm(GEMM_NN, dY, W[lp + '0.fn.to_out.0.weight'], a['dattn'], M, d, d, d, d, d)
+            if self.dtype == torch.bfloat16:
+                check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
+                                             dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
+            else:
+                self._attn_bwd_f32(L, B, ph, s0 + 1)
+            self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M)
+            hip.gemm(GEMM_NN, a['dqkv'], W[lp + '0.fn.to_qkv.weight'], a['dxn'], M, d, 3 * d, 3 * d, d, d)
+            self._ln_bwd(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
+                         G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M)
+            dX, other = other, dX
+        # ---- embedding backward
+        check(l.ecgvit_embed_bwd(ptr(dX), ptr(a['dtok']), ptr(G[pre + 'cls_token']), ptr(G[pre + 'pos_embedding']), B, n, d, pe,
+                                 seed + 1, T, st), 'embed_bwd')
+        self._colsum(a['dtok'], d, G[pre + 'to_patch_embedding.1.bias'], Mp, d)
+        self._wgrad(a['dtok'], a['patches'], pre + 'to_patch_embedding.1.weight', d, self.CP, Mp)
+
+    def _attn_bwd_f32(self, L, B, ph, seed):
+        d, h, dh, N = self.d, self.h, self.dh, self.N
+        a = self.act
+        qkv, P, dqkv, dO, dP = L['qkv'], L['probs'], a['dqkv'], a['dattn'], a['dp']
+        sq, so, sp = (N * 3 * d, dh), (N * d, dh), (h * N * N, N * N)
+        Pd = P
+        if ph > 0:
+            Pd = a['pd']
+            self._drop_apply_f32(P, Pd, B * h * N * N, ph, seed)
+        # dV = Pd^T dO
+        hip.gemm(GEMM_TN, Pd, dO, dqkv, N, dh, N, N, d, 3 * d, batch=(B, h), strideA=sp, strideB=so, strideC=sq, c_off=2 * d)
+        # dPd = dO V^T
+        hip.gemm(GEMM_NT, dO, qkv, dP, N, N, dh, d, 3 * d, N, batch=(B, h), strideA=so, strideB=sq, strideC=sp, b_off=2 * d)
+        if ph > 0:
+            self._drop_apply_f32(dP, dP, B * h * N * N, ph, seed)
+        # dS = P * (dP - rowsum(P dP)) * scale
+        check(lib().ecgvit_softmax_bwd_rows(ptr(P), ptr(dP), B * h * N, N, N, self.scale, stream()), 'softmax_bwd_rows')
+        # dQ = dS K ; dK = dS^T Q
+        hip.gemm(GEMM_NN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, b_off=d)
+        hip.gemm(GEMM_TN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, c_off=d)
+
+    # ---------------------------------------------------------------- per-layer attention probabilities (f3)
+    def attention_probs(self, layer):
+        """Post-softmax attention of `layer` for the last forward, (B, h, N, N) f32 -- what vit_pytorch's Recorder hooks
+        (reference ecg_vit.py:176-194). f32 engine only (the bf16 path never materialises the scores)."""
+        if self.dtype != torch.float32:
+            raise RuntimeError('attention probabilities are only materialised on the float32 path')
+        B = self.saved['B']
+        return self.act['layers'][layer]['probs'].view(B, self.h, self.N, self.N)

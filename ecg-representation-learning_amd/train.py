@@ -1,0 +1,189 @@
+"""
+Train-step contract of the reference trainer, on the HIP engine.
+
+Mirrors `ecg_transformer/models/train.py`:
+  get_train_args (:407-436)  -- same defaults, same `steps_per_epoch = ceil(n_train // bsz)` floor-first quirk (:433)
+  the optimiser / scheduler wiring of MyTrainer.train (:241-252)
+  the step body (:268-283): zero_grad -> forward -> backward -> clip_grad_norm_(1.0, error_if_nonfinite) -> AdamW -> sched
+
+`HipTrainStep` runs that body fused on flat HBM buffers: one sum-of-squares pass over the flat gradient, one
+clip+AdamW pass that also refreshes the bf16 weight shadow, no per-parameter launches and no host sync in the step
+(the non-finite check of `error_if_nonfinite=True` is evaluated one step late from a device flag, or immediately with
+`sync_nonfinite=True`).  Data parallel (reference has none): one process per GPU, gradients all-reduced over
+RCCL as ONE collective over the flat gradient buffer (342 MB f32 for base: bandwidth-, not latency-bound on xGMI).
+
+Logging / TensorBoard / sklearn metrics / datasets of MyTrainer are host-side and out of scope here.
+"""
+import math
+import sys
+
+import torch
+import torch.distributed as dist
+
+from .check_args import ca
+from . import hip
+
+
+def get_train_args(args=None, n_train=None):
+    default_args = dict(
+        num_train_epoch=3,
+        train_batch_size=64,
+        eval_batch_size=64,
+        do_eval=True,
+        optimizer='AdamW',
+        learning_rate=3e-4,
+        weight_decay=1e-2,
+        warmup_ratio=0.05,
+        schedule='cosine',
+        n_sample=None,
+        augment_timeout=False,
+        patience=8,
+        precision=16 if torch.cuda.is_available() else 'bf16',  # carried, unused by the reference's live trainer too
+        log_per_epoch=False,
+        log_to_console=True,
+        save_every_n_epoch=False,
+        save_top_k=-1,
+        tqdm=False
+    )
+    args_ = default_args
+    if args is not None:
+        args_.update(args)
+    args_['steps_per_epoch'] = steps_per_epoch = math.ceil((n_train or int(sys.maxsize)) // args_['train_batch_size'])
+    args_['n_step'] = steps_per_epoch * args_['num_train_epoch']
+    ca(optimizer=args_['optimizer'], schedule=args_['schedule'])
+    return args_
+
+
+def lr_multiplier(schedule, n_warmup, n_step):
+    """HF get_constant_schedule_with_warmup / get_cosine_schedule_with_warmup (num_cycles=0.5) lambdas (train.py:245-252)."""
+    ca(schedule=schedule)
+
+    def f(step):
+        if step < n_warmup:
+            return float(step) / float(max(1, n_warmup))
+        if schedule == 'constant':
+            return 1.0
+        progress = float(step - n_warmup) / float(max(1, n_step - n_warmup))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+    return f
+
+
+class HipTrainStep:
+    """
+    step(sample_values, labels) == reference train.py:271-283 for one batch, fused.
+
+    args: dict as produced by `get_train_args` (uses optimizer, learning_rate, weight_decay, warmup_ratio, schedule, n_step).
+    """
+
+    def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=False, process_group=None):
+        self.model = model
+        self.args = {**get_train_args(), **(args or dict())}
+        ca(optimizer=self.args['optimizer'], schedule=self.args['schedule'])
+        self.lr0, self.wd = self.args['learning_rate'], self.args['weight_decay']
+        n_step = self.args['n_step']
+        self.mult = lr_multiplier(self.args['schedule'], round(n_step * self.args['warmup_ratio']), n_step)
+        self.decoupled = self.args['optimizer'] == 'AdamW'
+        self.max_grad_norm = max_grad_norm
+        self.sync_nonfinite = sync_nonfinite
+        self.step_count = 0       # optimiser steps taken == scheduler.step() calls
+        self.m = self.v = None
+        self.norm_out = self.sumsq = self.ws = None
+        self.last_loss = None
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    # -- lr as the reference logs it: scheduler.get_last_lr() after `step_count` scheduler steps
+    def get_last_lr(self):
+        return self.lr0 * self.mult(self.step_count)
+
+    def _state(self):
+        m = self.model
+        m._engine()
+        if self.m is None or self.m.device != m._pflat.device or self.m.numel() != m._pflat.numel():
+            self.m = torch.zeros_like(m._pflat)
+            self.v = torch.zeros_like(m._pflat)
+            self.norm_out = torch.zeros(2, device=m._pflat.device, dtype=torch.float32)
+            self.sumsq = torch.zeros(1, device=m._pflat.device, dtype=torch.float32)
+            self.ws = torch.empty(hip.lib().ecgvit_sumsq_workspace(m._pflat.numel()), device=m._pflat.device, dtype=torch.uint8)
+
+    # -- gradient all-reduce (RCCL over xGMI): one collective over the flat gradient buffer
+    def _allreduce(self, gflat):
+        if self.world == 1:
+            return
+        dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def step(self, sample_values, labels):
+        model = self.model
+        if not model.training:
+            raise RuntimeError('train step on a model in eval mode')
+        self._state()
+        self._raise_if_flagged()
+        eng = model._engine()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model._has_dropout else 0
+        x = sample_values.contiguous().float()
+        y = labels.contiguous().float()
+        w = None
+        if model.loss_weight:
+            w = torch.tensor(model.loss_weight, device=y.device, dtype=torch.float32)[y.long()].contiguous()
+        logits, _, loss_mean = eng.forward(x, y, w, training=True, seed=seed, want_mean=True)
+        model._fwd_id += 1
+        B, K = x.shape[0], eng.K
+        eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
+        gflat = model._gflat
+        self._allreduce(gflat)
+        l = hip.lib()
+        st = hip.stream()
+        hip.check(l.ecgvit_sumsq(gflat.data_ptr(), gflat.numel(), self.sumsq.data_ptr(), self.ws.data_ptr(), st), 'sumsq')
+        self.step_count += 1
+        lr = self.lr0 * self.mult(self.step_count - 1)  # lr in effect for this optimiser step
+        hip.check(l.ecgvit_adamw_step(
+            model._pflat.data_ptr(), gflat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+            model._wlow.data_ptr() if model._wlow is not None else None, gflat.numel(), self.sumsq.data_ptr(),
+            1.0 / self.world, self.max_grad_norm, lr, 0.9, 0.999, 1e-8, self.wd, self.step_count, 1 if self.decoupled else 0,
+            self.norm_out.data_ptr(), st), 'adamw_step')
+        self._flag_pending = True
+        if self.sync_nonfinite:
+            self._raise_if_flagged()
+        self.last_loss = loss_mean
+        return loss_mean, logits
+
+    def _one(self, device):
+        if getattr(self, '_one_t', None) is None or self._one_t.device != device:
+            self._one_t = torch.ones(1, device=device, dtype=torch.float32)
+        return self._one_t
+
+    _flag_pending = False
+
+    def _raise_if_flagged(self):
+        """`clip_grad_norm_(..., error_if_nonfinite=True)` semantics; the kernel skipped the update when the norm was non-finite."""
+        if self._flag_pending:
+            self._flag_pending = False
+            norm, finite = self.norm_out.tolist()
+            if finite == 0.0:
+                raise RuntimeError(f'The total norm for gradients is non-finite ({norm}), so it cannot be clipped.')
+
+    def grad_norm(self):
+        """pre-clip global gradient L2 norm of the last step (device sync)"""
+        return float(self.norm_out[0].item())
+
+
+def clip_grad_norm_(model, max_norm=1.0, error_if_nonfinite=True):
+    """`nn.utils.clip_grad_norm_` for the torch-optimizer interop path, on the model's flat gradient buffer (one
+    sum-of-squares pass + one scale pass instead of ~150 per-parameter launches). Requires `p.grad` to be the
+    engine's gradient views (true after `loss.backward()` when `zero_grad(set_to_none=True)` preceded it)."""
+    l = hip.lib()
+    g = model._gflat
+    for n, p in zip(model._param_names, model._param_list):  # grads that autograd cloned are copied back into the flat buffer
+        if p.grad is not None and p.grad.data_ptr() != g.data_ptr() + 4 * model._layout.entries[n][0]:
+            model._layout.view(g, n).copy_(p.grad)
+            p.grad = model._layout.view(g, n)
+    ws = torch.empty(l.ecgvit_sumsq_workspace(g.numel()), device=g.device, dtype=torch.uint8)
+    sumsq = torch.empty(1, device=g.device, dtype=torch.float32)
+    out = torch.empty(2, device=g.device, dtype=torch.float32)
+    hip.check(l.ecgvit_sumsq(g.data_ptr(), g.numel(), sumsq.data_ptr(), ws.data_ptr(), hip.stream()), 'sumsq')
+    hip.check(l.ecgvit_clip_scale(g.data_ptr(), g.numel(), sumsq.data_ptr(), float(max_norm), out.data_ptr(), hip.stream()),
+              'clip_scale')
+    norm, finite = out.tolist()
+    if error_if_nonfinite and finite == 0.0:
+        raise RuntimeError('The total norm for gradients is non-finite, so it cannot be clipped.')
+    return out[0]

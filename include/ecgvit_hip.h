@@ -1,0 +1,200 @@
+/*
+ * ecgvit_hip.h -- C-ABI of libecgvit_hip.so: the MI355X (gfx950) kernels behind the ECG-ViT train step.
+ *
+ * The reference (StefanHeng/ECG-Representation-Learning) has NO FFI / operator registry for this path:
+ * its boundary is the Python class surface `EcgVitConfig` / `EcgVit.forward` (ecg_transformer/models/
+ * ecg_vit.py:26-149) and the train-step body (ecg_transformer/models/train.py:268-283), and every
+ * numeric op below is one the reference reaches through third-party `vit-pytorch==0.33.2` -> `torch.nn`
+ * (reference call sites cited per entry point).  This header is therefore the build's own design for
+ * what sits UNDER that Python surface; `INTEGRATION.md` shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless named `h_*`.
+ *   - the caller owns every buffer (PyTorch caching allocator in the shipped host code); kernels never
+ *     allocate, never synchronise, keep no global state, and are stream-ordered on `stream`
+ *     (a `hipStream_t` passed as `void*`; NULL = the legacy default stream).
+ *   - return 0 on success; ECGVIT_EINVAL for an unsupported shape/argument (nothing launched);
+ *     ECGVIT_ELAUNCH if hipGetLastError() reported a launch failure.  Nothing throws across the ABI.
+ *   - `dtype` selects the ACTIVATION element type: ECGVIT_F32 (parity path, exact-f32 MFMA / VALU) or
+ *     ECGVIT_BF16 (throughput path, bf16 MFMA with f32 accumulate).  Parameters, gradients, optimiser
+ *     state, LayerNorm statistics, logits and losses are always f32.
+ *   - row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef ECGVIT_HIP_H
+#define ECGVIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECGVIT_OK 0
+#define ECGVIT_EINVAL 1
+#define ECGVIT_ELAUNCH 2
+
+#define ECGVIT_F32 0
+#define ECGVIT_BF16 1
+
+/* library / build identification: "ecgvit-hip gfx950 <abi-version>" */
+const char *ecgvit_version(void);
+int ecgvit_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMM: C[M,N] = epilogue( alpha * op(A) . op(B) )            (f32 accumulate)
+ * replaces: nn.Linear forward/backward reached from vit_pytorch Attention.to_qkv / to_out / FeedForward.net
+ * (reference ecg_vit.py:141 -> ViT.forward) and, in the f32 parity path, the batched QK^T / PV products.
+ * ------------------------------------------------------------------------------------------------ */
+#define ECGVIT_GEMM_NT 0 /* A[M,K] row-major, B[N,K] row-major :  C = A . B^T   (Linear forward)      */
+#define ECGVIT_GEMM_NN 1 /* A[M,K] row-major, B[K,N] row-major :  C = A . B     (Linear input grad)   */
+#define ECGVIT_GEMM_TN 2 /* A[K,M] row-major, B[K,N] row-major :  C = A^T . B   (Linear weight grad)  */
+
+/* epilogue flags; applied in this order to v = alpha * acc */
+#define ECGVIT_EPI_BIAS 1       /* v += bias[n]                                    (f32 bias)        */
+#define ECGVIT_EPI_GELU 2       /* aux[m,n] = v ; v = gelu_erf(v)                  (exact erf GELU)  */
+#define ECGVIT_EPI_GELU_BWD 4   /* v *= gelu_erf'(aux[m,n])                                          */
+#define ECGVIT_EPI_RESIDUAL 8   /* v += residual[m,n]                                                */
+#define ECGVIT_EPI_ACCUM 16     /* v += C[m,n]   (read-modify-write of the output)                   */
+#define ECGVIT_EPI_DROPOUT 32   /* v = keep(seed, m*N+n) ? v / (1-p) : 0 ; applied after GELU / GELU_BWD,
+                                   before RESIDUAL (the mask is a pure function of (seed, element))   */
+
+typedef struct ecgvit_gemm_desc {
+    int32_t layout;    /* ECGVIT_GEMM_*                                             */
+    int32_t dtype;     /* element type of A and B: ECGVIT_F32 | ECGVIT_BF16         */
+    int32_t out_dtype; /* element type of C, aux, residual                          */
+    int32_t epilogue;  /* OR of ECGVIT_EPI_*                                        */
+    int32_t M, N, K;
+    int32_t batch1, batch2; /* batched problems: z = z1 * batch2 + z2 (both >= 1)   */
+    const void *A; int64_t lda, strideA1, strideA2;
+    const void *B; int64_t ldb, strideB1, strideB2;
+    void *C;       int64_t ldc, strideC1, strideC2;
+    const float *bias;                    /* [N] f32                                 */
+    const void *residual; int64_t ldr;    /* [M,N] out_dtype (not batched)           */
+    void *aux;            int64_t ldaux;  /* [M,N] out_dtype (not batched)           */
+    float alpha;
+    float dropout_p;      /* in [0,1)                                                */
+    uint64_t dropout_seed;
+    void *workspace;      /* optional split-K slabs (bf16 TN); see ecgvit_gemm_workspace */
+    int64_t workspace_bytes;
+} ecgvit_gemm_desc;
+
+int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
+/* bytes of workspace with which the call would use its preferred split-K factor (0 = none needed) */
+int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d);
+
+/* ------------------------------------------------------------------------------------------------
+ * patch embedding front end.  replaces: einops Rearrange('b c (h p1) (w p2) -> b (h w) (p1 p2 c)')
+ * inside vit_pytorch ViT.to_patch_embedding (reference ecg_vit.py:141, shape probe :277).
+ * ------------------------------------------------------------------------------------------------ */
+/* patches[(b*n + p) * ld + j*C + c] = x[b][c][p*P + j]; columns [C*P, ld) are zero-filled. x is f32. */
+int ecgvit_patch_gather(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream);
+/* X[b*N + 0] = cls + pos[0];  X[b*N + 1 + p] = tok[b*n + p] + pos[1 + p]   (N = n + 1; ViT.forward: cat CLS, += pos)
+ * optional embedding dropout (p = emb_dropout_p, mask = f(seed, element index in X)). cls/pos are f32. */
+int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, void *X, int B, int n, int d,
+                        float dropout_p, uint64_t seed, int dtype, void *stream);
+/* backward of embed_finish: dtok[b*n+p] = dX[b*N+1+p] ; dpos[t] = sum_b dX[b*N+t] ; dcls = sum_b dX[b*N] (f32 grads, overwritten) */
+int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B, int n, int d,
+                     float dropout_p, uint64_t seed, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (eps 1e-5, biased variance, affine).  replaces: vit_pytorch PreNorm.norm / mlp_head[0].
+ * ------------------------------------------------------------------------------------------------ */
+int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                         int64_t rows, int d, float eps, int dtype, void *stream);
+/* dx = (dres ? dres : 0) + LN'(dy) ; dgamma/dbeta are OVERWRITTEN with the full reduction over rows.
+ * `partial` is caller workspace of ecgvit_layernorm_bwd_workspace(rows, d) bytes. */
+int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d);
+int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
+                         const void *dres, void *dx, float *dgamma, float *dbeta, void *partial,
+                         int64_t rows, int d, int dtype, void *stream);
+
+/* out[i] = in[i] * keep(seed, i) / (1-p): re-applies an epilogue dropout mask (element index = m*N+n, contiguous [M,N])
+ * to the incoming gradient of a `dropout(acc + bias) + residual` site.  in == out allowed. */
+int ecgvit_dropout_apply(const void *in, void *out, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream);
+
+/* out[n] = sum_m in[m,n]  (bias gradients).  `partial`: ecgvit_colsum_workspace(M,N) bytes. */
+int64_t ecgvit_colsum_workspace(int64_t M, int N);
+int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t M, int N, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-head self-attention core, fused (bf16 path).  replaces vit_pytorch Attention.forward between
+ * to_qkv and to_out: split heads, dots = q k^T * dh^-0.5, softmax, (dropout), attn v, merge heads.
+ * qkv: [B*N, 3*h*dh] (columns [q | k | v], head-major inside each) ; out: [B*N, h*dh] ; lse: [B,h,N] f32.
+ * bf16 path requires dh == 64; forward N <= 512 (online softmax over 32-key tiles), backward N <= 256.
+ * ------------------------------------------------------------------------------------------------ */
+int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale,
+                         float dropout_p, uint64_t seed, int dtype, void *stream);
+int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                         int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
+                         void *stream);
+/* f32 parity path pieces (scores materialised; the GEMMs are ecgvit_gemm batched calls):
+ * in-place row softmax of S[rows, ld] over the first N columns; optional export is the buffer itself. */
+int ecgvit_softmax_rows(float *S, int64_t rows, int N, int64_t ld, void *stream);
+/* dS = P * (dP - rowsum(P*dP)) * scale, written over dP */
+int ecgvit_softmax_bwd_rows(const float *P, float *dP, int64_t rows, int N, int64_t ld, float scale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * classification head + loss.  replaces: x[:,0] -> mlp_head (LayerNorm, Linear(d,K)) and
+ * nn.BCEWithLogitsLoss (reference ecg_vit.py:118, :144-148).
+ * ------------------------------------------------------------------------------------------------ */
+/* logits[b,c] = LN(X[b*N+0]) . W[c,:] + bias[c] ; saves xhat [B,d] f32 and rstd [B] for backward */
+int ecgvit_head_fwd(const void *X, int N, const float *gamma, const float *beta, const float *W, const float *bias,
+                    float *logits, float *xhat, float *rstd, int B, int d, int K, float eps, int dtype, void *stream);
+/* elementwise l = w * (max(z,0) - z*y + log1p(exp(-|z|))) ; loss_elem [B*K] always written;
+ * loss_mean (1 f32) = mean(l) if non-NULL.  weight may be NULL.  Deterministic single-pass reduction. */
+int ecgvit_bce_fwd(const float *logits, const float *labels, const float *weight, float *loss_elem, float *loss_mean,
+                   int64_t count, void *stream);
+/* dlogits = upstream * w * (sigmoid(z) - y) ; upstream = *gscalar * gscale (gelem NULL) or gelem[i] * gscale */
+int ecgvit_bce_bwd(const float *logits, const float *labels, const float *weight, const float *gscalar,
+                   const float *gelem, float gscale, float *dlogits, int64_t count, void *stream);
+/* backward of head_fwd: dW,dbias,dgamma,dbeta overwritten; dX [B*N, d] is ZERO-FILLED then CLS rows written */
+int ecgvit_head_bwd(const float *dlogits, const float *xhat, const float *rstd, const float *gamma, const float *beta,
+                    const float *W, float *dW, float *dbias, float *dgamma, float *dbeta, void *dX, int N, int B, int d,
+                    int K, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * optimiser: global-norm clip + AdamW/Adam over FLAT f32 buffers.  replaces train.py:281-282
+ * (nn.utils.clip_grad_norm_(max_norm=1.0, error_if_nonfinite=True) + torch.optim.AdamW.step).
+ * ------------------------------------------------------------------------------------------------ */
+int64_t ecgvit_sumsq_workspace(int64_t count);
+/* out[0] = sum(g^2) (f32, deterministic two-stage) ; `partial` = ecgvit_sumsq_workspace(count) bytes */
+int ecgvit_sumsq(const float *g, int64_t count, float *out, void *partial, void *stream);
+/* norm = |grad_scale| * sqrt(sumsq[0]) ; coef = min(1, max_norm / (norm + 1e-6)) (coef = 1 if max_norm <= 0);
+ * g' = g * grad_scale * coef ; AdamW: p *= 1 - lr*wd ; Adam: g' += wd * p ; m,v update ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ * norm_out[0] = norm (pre-clip, of grad_scale-scaled grads), norm_out[1] = 1.0 if norm is finite else 0.0;
+ * when the norm is non-finite NOTHING is updated (caller raises, as error_if_nonfinite=True does).
+ * p_lowp: optional bf16 shadow copy of p, refreshed in the same pass. */
+int ecgvit_adamw_step(float *p, const float *g, float *m, float *v, void *p_lowp, int64_t count,
+                      const float *sumsq, float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, int decoupled, float *norm_out, void *stream);
+/* g *= min(1, max_norm/(norm+1e-6)) in place (torch-optimizer interop path); norm_out as above */
+int ecgvit_clip_scale(float *g, int64_t count, const float *sumsq, float max_norm, float *norm_out, void *stream);
+int ecgvit_cast_f32_to_bf16(const float *src, void *dst, int64_t count, void *stream);
+int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * masked pre-train objective (build's own definition; absent from the reference)
+ * ------------------------------------------------------------------------------------------------ */
+/* tok[b*n + idx[b,k]] = mask_token for k < m (idx int32, distinct per record) then X = tok + pos[1..n] (no CLS row).
+ * flag_ws: caller scratch of B*n bytes. */
+int ecgvit_mask_embed_finish(const void *tok, const float *mask_token, const float *pos, const int32_t *idx, void *X,
+                             void *flag_ws, int B, int n, int m, int d, int dtype, void *stream);
+/* gather rows: out[b*m + k] = in[b*n + idx[b,k]] */
+int ecgvit_gather_rows(const void *in, const int32_t *idx, void *out, int B, int n, int m, int64_t width, int64_t ld_in,
+                       int64_t ld_out, int dtype, void *stream);
+/* scatter-add rows (distinct idx per record => plain stores into a zero-filled buffer) */
+int ecgvit_scatter_rows(const void *in, const int32_t *idx, void *out, int B, int n, int m, int64_t width,
+                        int64_t ld_in, int64_t ld_out, int dtype, void *stream);
+/* L1 reconstruction loss: loss[0] = mean |pred - target| ; dpred = upstream * sign(pred - target) / count */
+int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, void *dpred, const float *gscalar,
+                           int64_t rows, int width, int64_t ld, int dtype, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * probes used by tests to pin hardware fragment layouts with exact integer data
+ * ------------------------------------------------------------------------------------------------ */
+int ecgvit_probe_mfma_layout(float *out /* [4][64][16] */, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECGVIT_HIP_H */

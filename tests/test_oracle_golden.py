@@ -1,0 +1,118 @@
+"""CPU: the oracle restatement against the fixtures produced by executing the reference's own files
+(oracle/make_golden.py).  Pins the reference-owned semantics: BCE (mean/none/weighted), patch order,
+clip_grad_norm_ + AdamW + HF warm-up/cosine wiring of train.py:241-283."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Cfg, load_micro, GOLDEN
+from oracle import vit_oracle as O
+
+TAGS = ['g2560', 'g5000', 't128']
+
+
+def build(tag):
+    z, spec = load_micro(tag)
+    model = O.OracleEcgVit(config=Cfg(**spec))
+    sd = {k[len('param/'):]: torch.from_numpy(z[k]) for k in z.files if k.startswith('param/')}
+    model.load_state_dict(sd, strict=True)
+    return z, spec, model
+
+
+def test_patch_gather_bit_exact():
+    z = np.load(os.path.join(GOLDEN, 'patch_gather.npz'))
+    for key in z.files:
+        L, P = (int(s[1:]) for s in key.split('_'))
+        x = np.arange(2 * 12 * L, dtype=np.float32).reshape(2, 12, L)
+        got = O.patch_gather_np(x, P).astype(np.int32)
+        assert np.array_equal(got, z[key]), key
+        got_t = O.patch_gather(torch.from_numpy(x), P).numpy().astype(np.int32)
+        assert np.array_equal(got_t, z[key]), key
+        # spot-check the closed form f = j*C + c
+        b, p, j, c = 1, 3, P - 1, 7
+        assert z[key][b, p, j * 12 + c] == int(x[b, c, p * P + j])
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_forward_loss_and_intermediates(tag):
+    z, spec, model = build(tag)
+    model.train()
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['y'])
+    inter = {}
+    hooks = [model.vit.to_patch_embedding.register_forward_hook(lambda m, i, o: inter.__setitem__('embed', o))]
+    for i, (attn, ff) in enumerate(model.vit.transformer.layers):
+        hooks.append(attn.fn.to_qkv.register_forward_hook(lambda m, a, o, i=i: inter.__setitem__(f'l{i}/qkv', o)))
+        hooks.append(ff.fn.net[1].register_forward_hook(lambda m, a, o, i=i: inter.__setitem__(f'l{i}/gelu', o)))
+        hooks.append(ff.register_forward_hook(lambda m, a, o, i=i: inter.__setitem__(f'l{i}/ff_out', o)))
+    out = model(sample_values=x, labels=y)
+    for h in hooks:
+        h.remove()
+    np.testing.assert_allclose(out.logits.detach().numpy(), z['logits'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(out.loss), float(z['loss_mean']), rtol=1e-6)
+    for k, v in inter.items():
+        np.testing.assert_allclose(v.detach().numpy(), z[f'inter/{k}'], rtol=1e-5, atol=1e-6, err_msg=k)
+    assert model(sample_values=x).loss is None
+    model.loss_reduction = 'none'
+    np.testing.assert_allclose(model(sample_values=x, labels=y).loss.detach().numpy(), z['loss_none'], rtol=1e-5, atol=1e-7)
+    model.loss_reduction = 'mean'
+    model.loss_weight = [1.0, 3.0]
+    np.testing.assert_allclose(float(model(sample_values=x, labels=y).loss), float(z['loss_weighted']), rtol=1e-6)
+
+
+@pytest.mark.parametrize('tag', TAGS)
+def test_train_steps(tag):
+    z, spec, model = build(tag)
+    model.train()
+    x, y = torch.from_numpy(z['x']), torch.from_numpy(z['y'])
+    tr = O.OracleTrainer(model, learning_rate=3e-4, weight_decay=1e-2, optimizer='AdamW', schedule='cosine',
+                         warmup_ratio=float(z['train/warmup_ratio']), n_step=int(z['train/n_step']))
+    for it in range(3):
+        out = tr.step(x, y)
+        if it == 0:
+            # gradients after clipping = golden raw grads * coef
+            norm = float(z['train/grad_norms'][0])
+            coef = min(1.0, 1.0 / (norm + 1e-6))
+            for k, p in model.named_parameters():
+                np.testing.assert_allclose(p.grad.numpy(), z[f'grad/{k}'] * coef, rtol=2e-4, atol=1e-7, err_msg=k)
+        np.testing.assert_allclose(float(out.loss), z['train/losses'][it], rtol=1e-5)
+        np.testing.assert_allclose(float(tr.last_grad_norm), z['train/grad_norms'][it], rtol=1e-4)
+        if it in (0, 2):
+            for k, v in model.state_dict().items():
+                np.testing.assert_allclose(v.numpy(), z[f'param_after{it + 1}/{k}'], rtol=1e-5, atol=3e-6, err_msg=k)  # Adam step <= lr on near-zero grads
+
+
+def test_manual_clip_and_adamw_match_torch():
+    """the hand-written clip / AdamW restatements (used to reason about the fused kernel) == torch's"""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = torch.optim.AdamW(ps, lr=1e-2, weight_decay=0.1)
+    state = {}
+    for step in range(1, 4):
+        gs = [torch.randn_like(p) * 3 for p in ps]
+        for p, q, g in zip(ps, qs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        n1 = torch.nn.utils.clip_grad_norm_(ps, 1.0, error_if_nonfinite=True)
+        n2 = O.clip_grad_norm(qs, 1.0)
+        assert torch.allclose(n1, n2)
+        opt.step()
+        O.adamw_step(qs, state, 1e-2, 0.1, step)
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, rtol=1e-6, atol=1e-7)
+    qs[0].grad = torch.full_like(qs[0], float('nan'))
+    with pytest.raises(RuntimeError):
+        O.clip_grad_norm(qs, 1.0)
+
+
+def test_masked_objective_oracle_runs_and_indexing():
+    cfg = Cfg(max_signal_length=200, patch_size=20, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64)
+    enc = O.OracleEcgVit(config=cfg)
+    mm = O.OracleMaskedEcgVit(enc)
+    x = torch.randn(3, 12, 200)
+    idx = torch.stack([torch.randperm(10)[:5] for _ in range(3)]).int()
+    out = mm(x, idx)
+    assert out.logits.shape == (3, 5, 240) and out.loss.ndim == 0
+    out.loss.backward()
+    assert mm.mask_token.grad is not None and enc.vit.cls_token.grad is None  # no CLS in the masked trunk
