@@ -1,0 +1,509 @@
+"""-m gpu: every C-ABI op against a CPU reference on the same seeded inputs (f32: <= 1e-5 relative, the noise of
+accumulation order; bf16: inputs rounded to bf16 first, outputs within bf16 rounding; integer indexing: bit-exact)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from hiputil import dev, rel_err, max_err, gelu, gelu_grad, lib, check, ptr, stream, hip
+from oracle import vit_oracle as O
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def test_fragment_layout_probe():
+    """pins row_frag / tr_frag32 (ds_read_b64_tr_b16) / the 32x32 accumulator map with exact integers"""
+    out = torch.zeros(4, 64, 16, device='cuda')
+    check(lib().ecgvit_probe_mfma_layout(ptr(out), stream()), 'probe')
+    o = out.cpu().numpy()
+    for lane in range(64):
+        r, h = lane & 31, lane >> 5
+        for j in range(8):
+            assert o[0, lane, j] == 2 * (32 + r), ('row_frag row', lane, j)
+            assert o[0, lane, 8 + j] == 16 + 8 * h + j, ('row_frag col', lane, j)
+            assert o[1, lane, j] == 2 * (16 + 8 * (j >> 2) + 4 * h + (j & 3)) + 1, ('tr_frag row', lane, j, o[1, lane, j])
+            assert o[1, lane, 8 + j] == 32 + r, ('tr_frag col', lane, j)
+        for reg in range(16):
+            assert o[2, lane, reg] == (reg & 3) + 8 * (reg >> 2) + 4 * h, ('acc row', lane, reg)
+            assert o[3, lane, reg] == r, ('acc col', lane, reg)
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM
+def _gemm_ref(layout, A, B):
+    A, B = A.double(), B.double()
+    if layout == hip.GEMM_NT:
+        return A @ B.T
+    if layout == hip.GEMM_NN:
+        return A @ B
+    return A.T @ B
+
+
+def _operands(layout, M, N, K, dtype, g):
+    shA = (K, M) if layout == hip.GEMM_TN else (M, K)
+    shB = (N, K) if layout == hip.GEMM_NT else (K, N)
+    A = torch.randn(*shA, generator=g).to(dtype)
+    B = torch.randn(*shB, generator=g).to(dtype)
+    return A, B
+
+
+@pytest.mark.parametrize('layout', [hip.GEMM_NT, hip.GEMM_NN, hip.GEMM_TN])
+@pytest.mark.parametrize('shape', [(37, 29, 19), (128, 128, 16), (200, 96, 70), (1, 5, 3), (300, 260, 130)])
+def test_gemm_f32_plain(layout, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 1000 + N * 10 + layout)
+    A, B = _operands(layout, M, N, K, F32, g)
+    C = torch.full((M, N), float('nan'), device='cuda')
+    hip.gemm(layout, dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N)
+    assert rel_err(C, _gemm_ref(layout, A, B)) < 2e-6
+
+
+def test_gemm_f32_epilogues():
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 70, 40, 33
+    A, B = _operands(hip.GEMM_NT, M, N, K, F32, g)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    base = _gemm_ref(hip.GEMM_NT, A, B)
+    # bias + gelu (aux = pre-activation) + residual, alpha
+    C, aux = torch.zeros(M, N, device='cuda'), torch.zeros(M, N, device='cuda')
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_RESIDUAL,
+             bias=dev(bias), residual=dev(res), ldr=N, aux=aux, ldaux=N, alpha=0.5)
+    pre = 0.5 * base + bias.double()
+    assert rel_err(aux, pre) < 2e-6
+    assert rel_err(C, gelu(pre) + res.double()) < 2e-6
+    # gelu backward multiply
+    C2 = torch.zeros(M, N, device='cuda')
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C2, M, N, K, K, K, N, epilogue=hip.EPI_GELU_BWD, aux=dev(res), ldaux=N)
+    assert rel_err(C2, base * gelu_grad(res)) < 2e-6
+    # accumulate
+    C3 = dev(res.clone())
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C3, M, N, K, K, K, N, epilogue=hip.EPI_ACCUM)
+    assert rel_err(C3, base + res.double()) < 2e-6
+
+
+def test_gemm_f32_batched_strided_heads():
+    """the attention use: q/k/v column slices of a [B*N, 3d] buffer, 2-level batch (record, head), odd N"""
+    g = torch.Generator().manual_seed(6)
+    B, N, h, dh = 3, 41, 2, 16
+    d = h * dh
+    qkv = torch.randn(B * N, 3 * d, generator=g)
+    S = torch.zeros(B * h * N * N, device='cuda')
+    sq = (N * 3 * d, dh)
+    hip.gemm(hip.GEMM_NT, dev(qkv), dev(qkv), S, N, N, dh, 3 * d, 3 * d, N, alpha=0.25, batch=(B, h), strideA=sq, strideB=sq,
+             strideC=(h * N * N, N * N), b_off=d)
+    q = qkv[:, :d].reshape(B, N, h, dh).permute(0, 2, 1, 3).double()
+    k = qkv[:, d:2 * d].reshape(B, N, h, dh).permute(0, 2, 1, 3).double()
+    v = qkv[:, 2 * d:].reshape(B, N, h, dh).permute(0, 2, 1, 3).double()
+    ref = 0.25 * q @ k.transpose(-1, -2)
+    assert rel_err(S.view(B, h, N, N), ref) < 2e-6
+    out = torch.zeros(B * N, d, device='cuda')
+    P = torch.softmax(ref, -1).float()
+    hip.gemm(hip.GEMM_NN, dev(P.reshape(-1)), dev(qkv), out, N, dh, N, N, 3 * d, d, batch=(B, h), strideA=(h * N * N, N * N),
+             strideB=sq, strideC=(N * d, dh), b_off=2 * d)
+    ref_o = (P.double() @ v).permute(0, 2, 1, 3).reshape(B * N, d)
+    assert rel_err(out, ref_o) < 2e-6
+    dq = torch.zeros(B * N, 3 * d, device='cuda')
+    hip.gemm(hip.GEMM_TN, dev(P.reshape(-1)), dev(qkv), dq, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=(h * N * N, N * N),
+             strideB=sq, strideC=sq, c_off=d)
+    ref_k = (P.double().transpose(-1, -2) @ q).permute(0, 2, 1, 3).reshape(B * N, d)
+    assert rel_err(dq[:, d:2 * d], ref_k) < 2e-6
+
+
+@pytest.mark.parametrize('layout', [hip.GEMM_NT, hip.GEMM_NN, hip.GEMM_TN])
+@pytest.mark.parametrize('shape', [(128, 128, 64), (300, 192, 128), (1000, 264, 240), (251, 768, 768), (64, 8, 8)])
+@pytest.mark.parametrize('out_dtype', [BF16, F32])
+def test_gemm_bf16_plain(layout, shape, out_dtype):
+    M, N, K = shape
+    if layout == hip.GEMM_TN:
+        M = (M + 7) // 8 * 8
+    g = torch.Generator().manual_seed(M + N + K + layout)
+    A, B = _operands(layout, M, N, K, BF16, g)
+    C = torch.full((M, N), float('nan'), device='cuda', dtype=out_dtype)
+    hip.gemm(layout, dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N)
+    ref = _gemm_ref(layout, A.float(), B.float())
+    assert torch.isfinite(C.float()).all()
+    assert rel_err(C, ref) < (4e-3 if out_dtype == BF16 else 2e-5)
+
+
+def test_gemm_bf16_splitk_wgrad():
+    g = torch.Generator().manual_seed(11)
+    Mout, Nin, rows = 256, 240, 5021  # rows: ragged contraction (zero-filled tail), split-K over the workspace
+    dY = torch.randn(rows, Mout, generator=g).to(BF16)
+    X = torch.randn(rows, Nin, generator=g).to(BF16)
+    need = hip.gemm_workspace_bytes(hip.GEMM_TN, BF16, Mout, Nin, rows)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    C = torch.full((Mout, Nin), float('nan'), device='cuda')
+    hip.gemm(hip.GEMM_TN, dev(dY), dev(X), C, Mout, Nin, rows, Mout, Nin, Nin, workspace=ws)
+    ref = dY.double().T @ X.double()
+    assert rel_err(C, ref) < 2e-5
+    C2 = torch.full((Mout, Nin), float('nan'), device='cuda')
+    hip.gemm(hip.GEMM_TN, dev(dY), dev(X), C2, Mout, Nin, rows, Mout, Nin, Nin)  # no workspace: single pass
+    assert rel_err(C2, ref) < 2e-5
+
+
+def test_gemm_bf16_epilogues():
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 260, 136, 128
+    A, B = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(BF16)
+    base = _gemm_ref(hip.GEMM_NT, A.float(), B.float())
+    C = torch.zeros(M, N, device='cuda', dtype=BF16)
+    aux = torch.zeros(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_GELU, bias=dev(bias), aux=aux, ldaux=N)
+    pre = base + bias.double()
+    assert rel_err(aux, pre) < 4e-3
+    assert rel_err(C, gelu(aux.float().double().cpu())) < 4e-3  # GELU of the STORED (bf16) pre-activation
+    C = torch.zeros(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_RESIDUAL, bias=dev(bias),
+             residual=dev(res), ldr=N)
+    assert rel_err(C, pre + res.double()) < 4e-3
+    C = torch.zeros(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C, M, N, K, K, K, N, epilogue=hip.EPI_GELU_BWD, aux=dev(res), ldaux=N)
+    assert rel_err(C, base * gelu_grad(res.float())) < 4e-3
+
+
+def test_gemm_dropout_epilogue_mask_is_reproducible():
+    """the epilogue mask is a pure function of (seed, element): forward epilogue == ecgvit_dropout_apply on the same index"""
+    g = torch.Generator().manual_seed(13)
+    M, N, K = 192, 136, 64
+    p, seed = 0.25, 1234
+    for dtype in (F32, BF16):
+        A, B = _operands(hip.GEMM_NT, M, N, K, dtype, g)
+        C0 = torch.zeros(M, N, device='cuda', dtype=dtype)
+        C1 = torch.zeros(M, N, device='cuda', dtype=dtype)
+        hip.gemm(hip.GEMM_NT, dev(A), dev(B), C0, M, N, K, K, K, N)
+        hip.gemm(hip.GEMM_NT, dev(A), dev(B), C1, M, N, K, K, K, N, epilogue=hip.EPI_DROPOUT, dropout_p=p, seed=seed)
+        C2 = torch.empty_like(C0)
+        check(lib().ecgvit_dropout_apply(ptr(C0), ptr(C2), M * N, p, seed, hip.code(dtype), stream()), 'dropout_apply')
+        keep = (C1 != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 0.02
+        if dtype == F32:
+            assert torch.equal(C1, C2)
+        else:  # bf16: the epilogue scales the f32 accumulator, dropout_apply the rounded value
+            assert torch.equal(C1 != 0, C2 != 0) and rel_err(C1, C2.float()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------------ row ops
+@pytest.mark.parametrize('geom', [(2560, 64), (5000, 20), (40, 10), (1000, 20)])
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_patch_gather_bit_exact(geom, dtype):
+    L, P = geom
+    B, C = 3, 12
+    g = torch.Generator().manual_seed(L)
+    x = torch.randn(B, C, L, generator=g)
+    ld = C * P
+    out = torch.full((B * (L // P), ld), float('nan'), device='cuda', dtype=dtype)
+    check(lib().ecgvit_patch_gather(ptr(dev(x)), ptr(out), B, C, L, P, ld, hip.code(dtype), stream()), 'patch_gather')
+    ref = torch.from_numpy(O.patch_gather_np(x.numpy(), P)).reshape(-1, ld).to(dtype)
+    assert torch.equal(out.cpu(), ref)
+    # arange input: pure integer pin, padded leading dimension zero-filled
+    xi = torch.arange(B * C * L, dtype=torch.float32).reshape(B, C, L)
+    ld2 = ld + 16
+    out2 = torch.full((B * (L // P), ld2), float('nan'), device='cuda')
+    check(lib().ecgvit_patch_gather(ptr(dev(xi)), ptr(out2), B, C, L, P, ld2, hip.F32, stream()), 'patch_gather')
+    assert torch.equal(out2[:, :ld].cpu(), torch.from_numpy(O.patch_gather_np(xi.numpy(), P)).reshape(-1, ld))
+    assert (out2[:, ld:] == 0).all()
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_embed_finish_and_bwd(dtype):
+    g = torch.Generator().manual_seed(3)
+    B, n, d = 5, 13, 64
+    N = n + 1
+    tok = torch.randn(B * n, d, generator=g).to(dtype)
+    cls, pos = torch.randn(d, generator=g), torch.randn(N, d, generator=g)
+    X = torch.zeros(B * N, d, device='cuda', dtype=dtype)
+    check(lib().ecgvit_embed_finish(ptr(dev(tok)), ptr(dev(cls)), ptr(dev(pos)), ptr(X), B, n, d, 0.0, 0, hip.code(dtype), stream()), 'ef')
+    ref = torch.cat([cls.expand(B, 1, d), tok.float().view(B, n, d)], 1) + pos
+    assert rel_err(X.view(B, N, d), ref) < (1e-6 if dtype == F32 else 4e-3)
+    dX = torch.randn(B * N, d, generator=g).to(dtype)
+    dtok = torch.zeros(B * n, d, device='cuda', dtype=dtype)
+    dcls, dpos = torch.zeros(d, device='cuda'), torch.zeros(N, d, device='cuda')
+    check(lib().ecgvit_embed_bwd(ptr(dev(dX)), ptr(dtok), ptr(dcls), ptr(dpos), B, n, d, 0.0, 0, hip.code(dtype), stream()), 'eb')
+    r = dX.float().view(B, N, d)
+    assert torch.equal(dtok.cpu().view(B, n, d), dX.view(B, N, d)[:, 1:])
+    assert rel_err(dpos, r.sum(0)) < 1e-5 and rel_err(dcls, r[:, 0].sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('d', [32, 128, 768, 1024, 2048])
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_layernorm_fwd_bwd(d, dtype):
+    g = torch.Generator().manual_seed(d)
+    rows = 203
+    x = (torch.randn(rows, d, generator=g) * 2 + 0.5).to(dtype)
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    y = torch.zeros(rows, d, device='cuda', dtype=dtype)
+    mean, rstd = torch.zeros(rows, device='cuda'), torch.zeros(rows, device='cuda')
+    check(lib().ecgvit_layernorm_fwd(ptr(dev(x)), ptr(dev(gamma)), ptr(dev(beta)), ptr(y), ptr(mean), ptr(rstd), rows, d, 1e-5,
+                                     hip.code(dtype), stream()), 'ln')
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    tol = 2e-6 if dtype == F32 else 4e-3
+    assert rel_err(y, yr) < tol
+    assert rel_err(mean, x.double().mean(1)) < 1e-5
+    dy = torch.randn(rows, d, generator=g).to(dtype)
+    dres = torch.randn(rows, d, generator=g).to(dtype)
+    yr.backward(dy.double())
+    ws = torch.empty(lib().ecgvit_layernorm_bwd_workspace(rows, d), dtype=torch.uint8, device='cuda')
+    for use_res in (False, True):
+        dx = torch.zeros(rows, d, device='cuda', dtype=dtype)
+        dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
+        check(lib().ecgvit_layernorm_bwd(ptr(dev(dy)), ptr(dev(x)), ptr(dev(gamma)), ptr(mean), ptr(rstd),
+                                         ptr(dev(dres)) if use_res else None, ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, d,
+                                         hip.code(dtype), stream()), 'lnb')
+        ref_dx = xr.grad + (dres.double() if use_res else 0)
+        assert rel_err(dx, ref_dx) < (1e-5 if dtype == F32 else 8e-3)
+        assert rel_err(dg, gr.grad) < 1e-5 and rel_err(db, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_colsum(dtype):
+    g = torch.Generator().manual_seed(8)
+    for (M, N) in ((1003, 72), (257, 3072), (5, 8)):
+        x = torch.randn(M, N, generator=g).to(dtype)
+        out = torch.zeros(N, device='cuda')
+        ws = torch.empty(lib().ecgvit_colsum_workspace(M, N), dtype=torch.uint8, device='cuda')
+        check(lib().ecgvit_colsum(ptr(dev(x)), N, ptr(out), ptr(ws), M, N, hip.code(dtype), stream()), 'colsum')
+        assert rel_err(out, x.double().sum(0)) < 1e-5
+
+
+def test_softmax_rows_fwd_bwd():
+    g = torch.Generator().manual_seed(9)
+    rows, N = 77, 251
+    S = torch.randn(rows, N, generator=g) * 3
+    Sd = dev(S.clone())
+    check(lib().ecgvit_softmax_rows(ptr(Sd), rows, N, N, stream()), 'softmax')
+    Pr = torch.softmax(S.double(), -1)
+    assert rel_err(Sd, Pr) < 2e-6
+    dP = torch.randn(rows, N, generator=g)
+    dPd = dev(dP.clone())
+    check(lib().ecgvit_softmax_bwd_rows(ptr(Sd), ptr(dPd), rows, N, N, 0.125, stream()), 'softmax_bwd')
+    ref = Pr * (dP.double() - (Pr * dP.double()).sum(-1, keepdim=True)) * 0.125
+    assert rel_err(dPd, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------ head / loss
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_head_bce_fwd_bwd(dtype):
+    g = torch.Generator().manual_seed(10)
+    B, N, d, K = 6, 7, 96, 71
+    X = torch.randn(B * N, d, generator=g).to(dtype)
+    gamma, beta = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    W, bias = torch.randn(K, d, generator=g) * 0.1, torch.randn(K, generator=g)
+    y = (torch.rand(B, K, generator=g) < 0.1).float()
+    wgt = torch.tensor([1.0, 3.0])[y.long()]
+    Xd = dev(X)
+    logits = torch.zeros(B, K, device='cuda')
+    xhat, rstd = torch.zeros(B, d, device='cuda'), torch.zeros(B, device='cuda')
+    args = [ptr(dev(gamma)), ptr(dev(beta)), ptr(dev(W)), ptr(dev(bias))]
+    gd, bd, Wd, biasd = dev(gamma), dev(beta), dev(W), dev(bias)
+    check(lib().ecgvit_head_fwd(ptr(Xd), N, ptr(gd), ptr(bd), ptr(Wd), ptr(biasd), ptr(logits), ptr(xhat), ptr(rstd), B, d, K, 1e-5,
+                                hip.code(dtype), stream()), 'head_fwd')
+    Xr = X.double().requires_grad_(True)
+    pr = [t.double().requires_grad_(True) for t in (gamma, beta, W, bias)]
+    cls_rows = Xr.view(B, N, d)[:, 0]
+    z = torch.nn.functional.layer_norm(cls_rows, (d,), pr[0], pr[1], 1e-5) @ pr[2].T + pr[3]
+    assert rel_err(logits, z) < 1e-5
+    for weight in (None, wgt):
+        le, lm = torch.zeros(B, K, device='cuda'), torch.zeros(1, device='cuda')
+        check(lib().ecgvit_bce_fwd(ptr(logits), ptr(dev(y)), ptr(dev(weight)) if weight is not None else None, ptr(le), ptr(lm), B * K,
+                                   stream()), 'bce')
+        ref_le = torch.nn.functional.binary_cross_entropy_with_logits(z, y.double(), weight=None if weight is None else weight.double(),
+                                                                      reduction='none')
+        assert rel_err(le, ref_le) < 1e-5 and abs(float(lm) - float(ref_le.mean())) < 1e-6
+    # backward through mean loss (weighted)
+    for p_ in [Xr] + pr:
+        p_.grad = None
+    ref_le.mean().backward()
+    dl = torch.zeros(B, K, device='cuda')
+    one = torch.ones(1, device='cuda')
+    check(lib().ecgvit_bce_bwd(ptr(logits), ptr(dev(y)), ptr(dev(wgt)), ptr(one), None, 1.0 / (B * K), ptr(dl), B * K, stream()), 'bce_bwd')
+    dW, dbias = torch.zeros(K, d, device='cuda'), torch.zeros(K, device='cuda')
+    dg, db = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
+    dX = torch.full((B * N, d), 7.0, device='cuda', dtype=dtype)
+    check(lib().ecgvit_head_bwd(ptr(dl), ptr(xhat), ptr(rstd), ptr(gd), ptr(bd), ptr(Wd), ptr(dW), ptr(dbias), ptr(dg), ptr(db), ptr(dX),
+                                N, B, d, K, hip.code(dtype), stream()), 'head_bwd')
+    tol = 1e-5 if dtype == F32 else 1e-2
+    assert rel_err(dW, pr[2].grad) < tol and rel_err(dbias, pr[3].grad) < tol
+    assert rel_err(dg, pr[0].grad) < tol and rel_err(db, pr[1].grad) < tol
+    assert rel_err(dX, Xr.grad) < tol
+    assert (dX.view(B, N, d)[:, 1:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------------------ attention (bf16, fused)
+def _attn_ref(qkv, B, N, h, dh, scale, mask=None):
+    d = h * dh
+    q, k, v = (qkv[:, i * d:(i + 1) * d].reshape(B, N, h, dh).permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) * scale
+    p = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    pd = p if mask is None else p * mask
+    o = (pd @ v).permute(0, 2, 1, 3).reshape(B * N, d)
+    return o, lse, p
+
+
+@pytest.mark.parametrize('N', [51, 251, 128, 256, 1, 33])
+def test_attention_bf16_fwd_bwd(N):
+    g = torch.Generator().manual_seed(N)
+    B, h, dh = 2, 3, 64
+    d = h * dh
+    scale = dh ** -0.5
+    qkv = (torch.randn(B * N, 3 * d, generator=g) * 1.5).to(BF16)
+    qd = dev(qkv)
+    out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
+    lse = torch.zeros(B * h * N, device='cuda')
+    check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, scale, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
+    qr = qkv.double().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(qr, B, N, h, dh, scale)
+    assert torch.isfinite(out.float()).all()
+    assert max_err(out, o_ref) < 2e-2 and rel_err(out, o_ref) < 1e-2
+    assert max_err(lse.view(B, h, N), lse_ref) < 2e-3
+    do = torch.randn(B * N, d, generator=g).to(BF16)
+    o_ref.backward(do.double())
+    dqkv = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=BF16)
+    check(lib().ecgvit_attention_bwd(ptr(qd), ptr(out), ptr(dev(do)), ptr(lse), ptr(dqkv), B, N, h, dh, scale, 0.0, 0, hip.BF16, stream()),
+          'attn_bwd')
+    assert torch.isfinite(dqkv.float()).all()
+    for i, nm in enumerate('qkv'):
+        got, ref = dqkv[:, i * d:(i + 1) * d], qr.grad[:, i * d:(i + 1) * d]
+        assert rel_err(got, ref) < 2e-2, (nm, rel_err(got, ref))
+
+
+def test_attention_bf16_long_forward_501():
+    """forward covers N <= 512 (seq = 500 patches + CLS, the 'large' long-record geometry)"""
+    g = torch.Generator().manual_seed(501)
+    B, h, dh, N = 1, 2, 64, 501
+    d = h * dh
+    qkv = torch.randn(B * N, 3 * d, generator=g).to(BF16)
+    out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
+    lse = torch.zeros(B * h * N, device='cuda')
+    check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, dh, dh ** -0.5, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
+    o_ref, lse_ref, _ = _attn_ref(qkv.double(), B, N, h, dh, dh ** -0.5)
+    assert rel_err(out, o_ref) < 1e-2 and max_err(lse.view(B, h, N), lse_ref) < 2e-3
+
+
+def test_attention_bf16_dropout_mask_consistent_fwd_bwd():
+    """V = identity exposes the dropped probabilities as the output; backward must use the same mask"""
+    B, h, dh, N = 1, 1, 64, 64
+    p, seed = 0.3, 99
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.zeros(N, 3 * dh)
+    qkv[:, :2 * dh] = torch.randn(N, 2 * dh, generator=g) * 0.5
+    qkv[:, 2 * dh:] = torch.eye(N)
+    qkv = qkv.to(BF16)
+    out = torch.zeros(N, dh, device='cuda', dtype=BF16)
+    lse = torch.zeros(N, device='cuda')
+    check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, dh, 0.125, p, seed, hip.BF16, stream()), 'attn_fwd')
+    o = out.float().cpu()
+    mask = (o != 0).double()
+    keep = mask.mean().item()
+    assert abs(keep - (1 - p)) < 0.03
+    qr = qkv.double().requires_grad_(True)
+    o_ref, _, P = _attn_ref(qr, B, N, h, dh, 0.125, mask=(mask / (1 - p)).view(1, 1, N, N))
+    assert rel_err(out, o_ref) < 1e-2
+    do = torch.randn(N, dh, generator=g).to(BF16)
+    o_ref.backward(do.double())
+    dqkv = torch.zeros(N, 3 * dh, device='cuda', dtype=BF16)
+    check(lib().ecgvit_attention_bwd(ptr(dev(qkv)), ptr(out), ptr(dev(do)), ptr(lse), ptr(dqkv), B, N, h, dh, 0.125, p, seed, hip.BF16,
+                                     stream()), 'attn_bwd')
+    assert rel_err(dqkv, qr.grad) < 3e-2
+
+
+# ------------------------------------------------------------------------------------------------------ optimiser
+def test_sumsq_clip_adamw_match_torch():
+    g = torch.Generator().manual_seed(21)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, weight_decay=0.1)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    plow = torch.zeros(n, device='cuda', dtype=BF16)
+    ws = torch.empty(lib().ecgvit_sumsq_workspace(n), dtype=torch.uint8, device='cuda')
+    ss, no = torch.zeros(1, device='cuda'), torch.zeros(2, device='cuda')
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * (0.01 if step == 2 else 1.0)  # step 2: norm < 1, no clipping
+        pt.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pt], 1.0, error_if_nonfinite=True)
+        opt.step()
+        gd = dev(gr)
+        check(lib().ecgvit_sumsq(ptr(gd), n, ptr(ss), ptr(ws), stream()), 'sumsq')
+        assert abs(float(ss) - float(gr.double().pow(2).sum())) / float(gr.double().pow(2).sum()) < 1e-5
+        check(lib().ecgvit_adamw_step(ptr(p), ptr(gd), ptr(m), ptr(v), ptr(plow), n, ptr(ss), 1.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 0.1, step, 1,
+                                      ptr(no), stream()), 'adamw')
+        assert abs(float(no[0]) - float(tn)) / float(tn) < 1e-5 and float(no[1]) == 1.0
+        assert max_err(p, pt.detach()) < 2e-6
+        assert torch.equal(plow.cpu(), p.cpu().to(BF16))
+    # non-finite gradient: flagged, nothing updated
+    gd = dev(torch.full((n,), float('nan')))
+    before = p.clone()
+    check(lib().ecgvit_sumsq(ptr(gd), n, ptr(ss), ptr(ws), stream()), 'sumsq')
+    check(lib().ecgvit_adamw_step(ptr(p), ptr(gd), ptr(m), ptr(v), None, n, ptr(ss), 1.0, 1.0, 1e-2, 0.9, 0.999, 1e-8, 0.1, 4, 1, ptr(no),
+                                  stream()), 'adamw')
+    assert float(no[1]) == 0.0 and torch.equal(p, before)
+    # Adam (coupled weight decay) variant + stand-alone clip
+    q0 = torch.randn(1000, generator=g)
+    qt = torch.nn.Parameter(q0.clone())
+    opt2 = torch.optim.Adam([qt], lr=1e-2, weight_decay=0.1)
+    gr = torch.randn(1000, generator=g)
+    qt.grad = gr.clone()
+    opt2.step()
+    q, m2, v2 = dev(q0.clone()), torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    gd = dev(gr)
+    check(lib().ecgvit_sumsq(ptr(gd), 1000, ptr(ss), ptr(ws), stream()), 'sumsq')
+    check(lib().ecgvit_adamw_step(ptr(q), ptr(gd), ptr(m2), ptr(v2), None, 1000, ptr(ss), 1.0, 0.0, 1e-2, 0.9, 0.999, 1e-8, 0.1, 1, 0, ptr(no),
+                                  stream()), 'adam')
+    assert max_err(q, qt.detach()) < 2e-6
+    check(lib().ecgvit_clip_scale(ptr(gd), 1000, ptr(ss), 1.0, ptr(no), stream()), 'clip')
+    assert rel_err(gd, gr / (gr.norm() + 1e-6)) < 1e-5
+
+
+def test_casts_roundtrip():
+    x = torch.randn(10007)
+    b = torch.zeros(10007, device='cuda', dtype=BF16)
+    check(lib().ecgvit_cast_f32_to_bf16(ptr(dev(x)), ptr(b), 10007, stream()), 'cast')
+    assert torch.equal(b.cpu(), x.to(BF16))
+    f = torch.zeros(10007, device='cuda')
+    check(lib().ecgvit_cast_bf16_to_f32(ptr(b), ptr(f), 10007, stream()), 'cast')
+    assert torch.equal(f.cpu(), x.to(BF16).float())
+
+
+# ------------------------------------------------------------------------------------------------------ masked-objective ops
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_masked_objective_ops(dtype):
+    g = torch.Generator().manual_seed(31)
+    B, n, m, d = 4, 25, 12, 64
+    tok = torch.randn(B * n, d, generator=g).to(dtype)
+    mt, pos = torch.randn(d, generator=g), torch.randn(n + 1, d, generator=g)
+    idx = torch.stack([torch.randperm(n, generator=g)[:m] for _ in range(B)]).int()
+    X = torch.zeros(B * n, d, device='cuda', dtype=dtype)
+    flag = torch.zeros(B * n, dtype=torch.uint8, device='cuda')
+    check(lib().ecgvit_mask_embed_finish(ptr(dev(tok)), ptr(dev(mt)), ptr(dev(pos)), ptr(dev(idx)), ptr(X), ptr(flag), B, n, m, d,
+                                         hip.code(dtype), stream()), 'mask_embed')
+    t = tok.float().view(B, n, d).clone()
+    for b in range(B):
+        t[b, idx[b].long()] = mt
+    ref = (t + pos[1:]).view(B * n, d)
+    assert rel_err(X, ref) < (1e-6 if dtype == F32 else 4e-3)
+    # bit-exact integer index handling: which rows were replaced
+    is_masked = torch.zeros(B, n, dtype=torch.bool)
+    is_masked.scatter_(1, idx.long(), True)
+    assert torch.equal(flag.cpu().view(B, n).bool(), is_masked)
+    out = torch.zeros(B * m, d, device='cuda', dtype=dtype)
+    check(lib().ecgvit_gather_rows(ptr(X), ptr(dev(idx)), ptr(out), B, n, m, d, d, d, hip.code(dtype), stream()), 'gather')
+    bi = torch.arange(B).unsqueeze(-1)
+    assert torch.equal(out.cpu().view(B, m, d), X.cpu().view(B, n, d)[bi, idx.long()])
+    back = torch.zeros(B * n, d, device='cuda', dtype=dtype)
+    check(lib().ecgvit_scatter_rows(ptr(out), ptr(dev(idx)), ptr(back), B, n, m, d, d, d, hip.code(dtype), stream()), 'scatter')
+    exp = torch.zeros(B, n, d, dtype=dtype)
+    exp[bi, idx.long()] = X.cpu().view(B, n, d)[bi, idx.long()]
+    assert torch.equal(back.cpu().view(B, n, d), exp)
+    pred, tgt = torch.randn(B * m, d, generator=g).to(dtype), torch.randn(B * m, d, generator=g).to(dtype)
+    loss, dpred = torch.zeros(1, device='cuda'), torch.zeros(B * m, d, device='cuda', dtype=dtype)
+    check(lib().ecgvit_l1_loss_fwd_bwd(ptr(dev(pred)), ptr(dev(tgt)), ptr(loss), ptr(dpred), None, B * m, d, d, hip.code(dtype), stream()), 'l1')
+    diff = pred.double() - tgt.double()
+    assert abs(float(loss) - float(diff.abs().mean())) < 1e-5
+    assert rel_err(dpred, torch.sign(diff) / diff.numel()) < (1e-6 if dtype == F32 else 4e-3)
