@@ -46,3 +46,13 @@ def load_micro(tag):
 def host_contract():
     with open(os.path.join(GOLDEN, 'host_contract.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_temporaries():
+    yield
+    try:
+        import hiputil
+        hiputil.release()
+    except Exception:
+        pass

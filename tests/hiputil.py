@@ -6,11 +6,20 @@ from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import lib, check, ptr, stream
 
 
+_keepalive = []  # device copies made by dev() stay alive until the test ends (raw pointers are handed to the C-ABI)
+
+
 def dev(t, dtype=None):
     t = torch.as_tensor(t)
     if dtype is not None:
         t = t.to(dtype)
-    return t.contiguous().cuda()
+    d = t.contiguous().cuda()
+    _keepalive.append(d)
+    return d
+
+
+def release():
+    _keepalive.clear()
 
 
 def rel_err(a, b):
