@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""
+bench.py -- 12-lead ECG records/sec for one train step of EcgVit (BASELINE.json metric), on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W                         (single process)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = the reference's step body (ecg_transformer/models/train.py:271-283) on one synthetic batch already
+resident in HBM: forward (patch-embed -> L x [LN, MHSA, LN, GELU-FFN] -> head) + BCE loss + backward + global-norm
+clip + AdamW [+ RCCL gradient all-reduce for N > 1], dropout active at the reference's default 0.1.
+Workload at every N: EcgVit-base, bf16 MFMA path, 512 records x 12 leads x 5000 samples per GPU, patch 20 (251 tokens)
+(BASELINE.json configs[2]/[3]; weak scaling: global batch = 512 * N).
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline      dominant kernel (the bf16 MFMA GEMM of the Linear forward passes): algorithmic FLOPs of its launches
+                / their HIP-event time measured inside the timed region, against the 2.5 PFLOP/s dense bf16 peak.
+  cpu_baseline  the CPU oracle's train step (torch eager f32, all host cores) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+CONFIGS = {
+    # name: (from_defined name | dict of fields, per-GPU batch)
+    'base': ('ecg-vit-base', 512),
+    'small': ('ecg-vit-small', 256),
+    'tiny': ('ecg-vit-tiny', 256),
+    'tiny2': (dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512), 32),
+}
+
+
+def make_config(E, name, patch, length, dropout):
+    spec, batch = CONFIGS[name]
+    conf = E.EcgVitConfig.from_defined(spec) if isinstance(spec, str) else E.EcgVitConfig(**spec)
+    conf.max_signal_length, conf.patch_size = length, patch
+    if dropout is not None:
+        conf.hidden_dropout_prob = conf.attention_probs_dropout_prob = dropout
+    return conf, batch
+
+
+class GemmProbe:
+    """HIP-event timing of every launch of ONE kernel symbol (layout, out dtype) inside the timed region."""
+
+    def __init__(self, hip, layout, out_dtype):
+        self.hip, self.layout, self.out_dtype = hip, layout, out_dtype
+        self.orig = hip.gemm
+        self.events, self.flops, self.bytes = [], 0.0, 0.0
+        self.enabled = False
+
+    def install(self):
+        probe = self
+
+        def gemm(layout, A, B, C, M, N, K, *a, **k):
+            hit = probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and A.dtype == torch.bfloat16
+            if hit:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            probe.orig(layout, A, B, C, M, N, K, *a, **k)
+            if hit:
+                e1.record()
+                probe.events.append((e0, e1))
+                probe.flops += 2.0 * M * N * K
+                probe.bytes += 2.0 * (M * K + N * K + M * N)
+        self.hip.gemm = gemm
+        import ecg_representation_learning_amd.engine as eng
+        self._eng_hip = eng.hip
+        eng.hip.gemm = gemm
+
+    def result(self):
+        if not self.events:
+            return None
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        n = len(self.events)
+        return dict(launches=n, avg_us=1e3 * ms / n, tflops=self.flops / (ms * 1e-3) / 1e12, alg_bytes_per_launch=self.bytes / n,
+                    flops_per_launch=self.flops / n)
+
+
+def cpu_baseline(conf, seconds_budget=25.0):
+    """the CPU oracle (torch eager f32 restatement of the reference step) on the host cores, bounded sample (~seconds_budget)"""
+    from oracle import vit_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    flops_rec = O.train_flops_per_record(conf)
+    torch.manual_seed(77)
+    model = O.OracleEcgVit(config=conf).train()
+    tr = O.OracleTrainer(model, n_step=100)
+    x1, y1 = O.synthetic_batch(1, length=conf.max_signal_length, seed=77)
+    # pick the thread count that runs a 1-record step fastest (torch eager does not scale to hundreds of threads)
+    best = None
+    for t in sorted({min(avail, c) for c in (16, 32, 64)}):
+        torch.set_num_threads(t)
+        tr.step(x1, y1)
+        t0 = time.perf_counter()
+        tr.step(x1, y1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (t, dt)
+    cores, t1 = best
+    torch.set_num_threads(cores)
+    b = max(1, min(32, int(seconds_budget * 0.5 / 2 / max(t1, 1e-3))))   # two timed steps in about half the budget
+    x, y = O.synthetic_batch(b, length=conf.max_signal_length, seed=77)
+    tr.step(x, y)  # warm-up at the timed shape
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget * 0.4 and n < 8):
+        tr.step(x, y)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=b * n / dt, unit='records/s', cores=cores, kind='port',
+                sample=f'{n} full train steps (fwd+BCE+bwd+clip+AdamW, torch eager f32) of the same model on {b} synthetic '
+                       f'12x{conf.max_signal_length} records, {cores} threads of {avail} available (fastest of 16/32/64 on a 1-record probe)',
+                tflops=b * n * flops_rec / dt / 1e12)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='base', choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--patch', type=int, default=20)
+    ap.add_argument('--length', type=int, default=5000)
+    ap.add_argument('--dropout', type=float, default=None, help='override (default: reference config default 0.1)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-probe', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import ecg_representation_learning_amd as E
+    from oracle import vit_oracle as O  # only: synthetic_batch helper + FLOP formula + the cpu_baseline leg
+    E.hip.lib()  # fail loudly if the HIP library is missing
+
+    conf, batch = make_config(E, args.config, args.patch, args.length, args.dropout)
+    batch = args.batch or batch
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    torch.manual_seed(77)  # identical initial weights on every rank
+    model = E.EcgVit(config=conf, compute_dtype=dtype).to(dev).train()
+    x, y = O.synthetic_batch(batch, length=conf.max_signal_length, seed=77 + rank)
+    x, y = x.to(dev), y.to(dev)
+    n_total = args.steps + args.warmup
+    step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total))
+
+    probe = None
+    if not args.no_probe and dtype == torch.bfloat16:
+        probe = GemmProbe(E.hip, E.hip.GEMM_NT, torch.bfloat16)
+        probe.install()
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step.step(x, y)
+    sync()
+    if probe:
+        probe.enabled = rank == 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step.step(x, y)
+    sync()
+    dt = time.perf_counter() - t0
+    if probe:
+        probe.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss)
+    step.finish()
+
+    if rank == 0:
+        flops_rec = O.train_flops_per_record(conf)
+        value = batch * world * args.steps / dt
+        out = {
+            'metric': '12-lead ECG records/sec pre-train step, ViT-Base bf16 @ 1/2/4/8 MI355X' if args.config == 'base'
+            else f'12-lead ECG records/sec train step, EcgVit-{args.config}',
+            'value': value, 'unit': 'records/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {
+                'workload': f'EcgVit-{args.config} supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW'
+                            f'{"+RCCL all-reduce" if world > 1 else ""}), dropout {conf.hidden_dropout_prob}, '
+                            f'{batch} records/GPU x 12 leads x {conf.max_signal_length} samples, patch {conf.patch_size} '
+                            f'({conf.max_signal_length // conf.patch_size + 1} tokens), random-init weights, inputs resident in HBM',
+                'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
+                'hidden': conf.hidden_size, 'layers': conf.num_hidden_layers, 'heads': conf.num_attention_heads,
+            },
+            'final_loss': final_loss,
+            'model_tflops_per_gpu': value / world * flops_rec / 1e12,
+            'mfma_frac_of_peak': value / world * flops_rec / 1e12 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS),
+        }
+        if probe:
+            r = probe.result()
+            if r:
+                out['roofline'] = {
+                    'kernel': 'gemm_bf16_kernel<A_KC=1,B_KC=1,bf16 out> (Linear forward: QKV / attn-out / FFN-up / FFN-down / patch-embed)',
+                    'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
+                    'traffic': None, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+                    'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
+                }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(conf)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

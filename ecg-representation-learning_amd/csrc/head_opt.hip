@@ -71,22 +71,49 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float *__restrict__ 
 }
 
 // ---- head backward ------------------------------------------------------------------------------
-// dW[k][c] = sum_b dl[b][k] * (xhat[b][c]*gamma[c] + beta[c]) ; dbias[k] = sum_b dl[b][k].  grid = K blocks.
-__global__ __launch_bounds__(256) void head_bwd_w_kernel(const float *__restrict__ dl, const float *__restrict__ xhat,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         float *__restrict__ dW, float *__restrict__ dbias, int B, int d, int K) {
+// With T[k][c] = sum_b dl[b][k] * xhat[b][c] and dbias[k] = sum_b dl[b][k]:
+//   dW[k][c] = gamma[c] * T[k][c] + beta[c] * dbias[k]
+//   dgamma[c] = sum_k W[k][c] * T[k][c]          (= sum_b dxn[b][c] * xhat[b][c],  dxn = dl . W)
+//   dbeta[c]  = sum_k W[k][c] * dbias[k]         (= sum_b dxn[b][c])
+// stage 1 (grid = K blocks) leaves T in the dW buffer; stage 2 (one thread per column) finishes all four.
+__global__ __launch_bounds__(256) void head_bwd_t_kernel(const float *__restrict__ dl, const float *__restrict__ xhat,
+                                                         float *__restrict__ T, float *__restrict__ dbias, int B, int d, int K) {
     const int k = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += 256) {
-        const float g = gamma[c], bt = beta[c];
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dl[(int64_t)b * K + k] * (xhat[(int64_t)b * d + c] * g + bt);
-        dW[(int64_t)k * d + c] = acc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int b = 0;
+        for (; b + 3 < B; b += 4) {
+            a0 += dl[(int64_t)b * K + k] * xhat[(int64_t)b * d + c];
+            a1 += dl[(int64_t)(b + 1) * K + k] * xhat[(int64_t)(b + 1) * d + c];
+            a2 += dl[(int64_t)(b + 2) * K + k] * xhat[(int64_t)(b + 2) * d + c];
+            a3 += dl[(int64_t)(b + 3) * K + k] * xhat[(int64_t)(b + 3) * d + c];
+        }
+        for (; b < B; ++b) a0 += dl[(int64_t)b * K + k] * xhat[(int64_t)b * d + c];
+        T[(int64_t)k * d + c] = (a0 + a1) + (a2 + a3);
     }
     if (threadIdx.x == 0) {
         float acc = 0.f;
         for (int b = 0; b < B; ++b) acc += dl[(int64_t)b * K + k];
         dbias[k] = acc;
     }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_finish_kernel(const float *__restrict__ W, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, const float *__restrict__ dbias,
+                                                              float *__restrict__ dW, float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta, int d, int K) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    const float g = gamma[c], bt = beta[c];
+    float ag = 0.f, ab = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float w = W[(int64_t)k * d + c], t = dW[(int64_t)k * d + c], db = dbias[k];
+        ag += w * t;
+        ab += w * db;
+        dW[(int64_t)k * d + c] = g * t + bt * db;
+    }
+    dgamma[c] = ag;
+    dbeta[c] = ab;
 }
 
 // per record: dxn = dl[b] . W ; LayerNorm backward on the CLS row ; writes dX[b*N+0]
@@ -113,23 +140,6 @@ __global__ __launch_bounds__(256) void head_bwd_x_kernel(const float *__restrict
     const float rs = rstd[b];
     T *o = dX + (int64_t)b * N * d;
     for (int c = threadIdx.x; c < d; c += 256) o[c] = from_f32<T>(rs * (g[c] - c1 - xhat[(int64_t)b * d + c] * c2));
-}
-
-// dgamma[c] = sum_b dxn[b][c] * xhat[b][c] ; dbeta[c] = sum_b dxn[b][c]   (dxn recomputed: B*d*K MACs, tiny)
-__global__ __launch_bounds__(256) void head_bwd_ln_kernel(const float *__restrict__ dl, const float *__restrict__ xhat,
-                                                          const float *__restrict__ W, float *__restrict__ dgamma,
-                                                          float *__restrict__ dbeta, int B, int d, int K) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
-    float ag = 0.f, ab = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float acc = 0.f;
-        for (int k = 0; k < K; ++k) acc += dl[(int64_t)b * K + k] * W[(int64_t)k * d + c];
-        ag += acc * xhat[(int64_t)b * d + c];
-        ab += acc;
-    }
-    dgamma[c] = ag;
-    dbeta[c] = ab;
 }
 
 // ---- optimiser ----------------------------------------------------------------------------------
@@ -249,9 +259,9 @@ int ecgvit_head_bwd(const float *dlogits, const float *xhat, const float *rstd, 
     hipStream_t s = as_stream(stream);
     const size_t esz = dtype == ECGVIT_F32 ? 4 : 2;
     if (hipMemsetAsync(dX, 0, (size_t)B * N * d * esz, s) != hipSuccess) return ECGVIT_ELAUNCH;
-    hipLaunchKernelGGL(head_bwd_w_kernel, dim3(K), dim3(256), 0, s, dlogits, xhat, gamma, beta, dW, dbias, B, d, K);
+    hipLaunchKernelGGL(head_bwd_t_kernel, dim3(K), dim3(256), 0, s, dlogits, xhat, dW, dbias, B, d, K);
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head_bwd_ln_kernel, dim3((d + 255) / 256), dim3(256), 0, s, dlogits, xhat, W, dgamma, dbeta, B, d, K);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, s, W, gamma, beta, dbias, dW, dgamma, dbeta, d, K);
     ECGVIT_CHECK_LAUNCH();
     const size_t lds = (size_t)(K + d + 4) * 4;
     if (dtype == ECGVIT_F32)

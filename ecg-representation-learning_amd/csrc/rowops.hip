@@ -229,15 +229,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
     }
 }
 
-// out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta)
+// out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta).
+// Block = 64 columns x 4 row-slices (each slice sums every 4th partial row, 4 loads in flight), LDS combine.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
                                                               float *__restrict__ out0, float *__restrict__ out1, int split) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * width + c];
-    if (c < split) out0[c] = s;
-    else out1[c - split] = s;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < width) {
+        int p = slice;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += partial[(int64_t)p * width + c];
+            s1 += partial[(int64_t)(p + 4) * width + c];
+            s2 += partial[(int64_t)(p + 8) * width + c];
+            s3 += partial[(int64_t)(p + 12) * width + c];
+        }
+        for (; p < nparts; p += 4) s0 += partial[(int64_t)p * width + c];
+    }
+    red[slice][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && c < width) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (c < split) out0[c] = s;
+        else out1[c - split] = s;
+    }
 }
 
 // =====================================================================================================
@@ -402,7 +418,7 @@ int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, cons
     else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 255) / 256), dim3(256), 0, as_stream(stream), (const float *)partial, grid, 2 * d, dgamma, dbeta, d);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, grid, 2 * d, dgamma, dbeta, d);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
@@ -423,7 +439,7 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)in, ld, (float *)partial, M, N, rpb);
     else return ECGVIT_EINVAL;
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

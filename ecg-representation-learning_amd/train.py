@@ -103,6 +103,8 @@ class HipTrainStep:
             self.m = torch.zeros_like(m._pflat)
             self.v = torch.zeros_like(m._pflat)
             self.norm_out = torch.zeros(2, device=m._pflat.device, dtype=torch.float32)
+            self.norm_host = torch.ones(2, dtype=torch.float32).pin_memory()
+            self._flag_event = torch.cuda.Event()
             self.sumsq = torch.zeros(1, device=m._pflat.device, dtype=torch.float32)
             self.ws = torch.empty(hip.lib().ecgvit_sumsq_workspace(m._pflat.numel()), device=m._pflat.device, dtype=torch.uint8)
 
@@ -141,9 +143,12 @@ class HipTrainStep:
             model._wlow.data_ptr() if model._wlow is not None else None, gflat.numel(), self.sumsq.data_ptr(),
             1.0 / self.world, self.max_grad_norm, lr, 0.9, 0.999, 1e-8, self.wd, self.step_count, 1 if self.decoupled else 0,
             self.norm_out.data_ptr(), st), 'adamw_step')
+        # non-blocking readback of (norm, finite flag) into pinned host memory; inspected when its event has completed
+        self.norm_host.copy_(self.norm_out, non_blocking=True)
+        self._flag_event.record()
         self._flag_pending = True
         if self.sync_nonfinite:
-            self._raise_if_flagged()
+            self._raise_if_flagged(wait=True)
         self.last_loss = loss_mean
         return loss_mean, logits
 
@@ -154,17 +159,25 @@ class HipTrainStep:
 
     _flag_pending = False
 
-    def _raise_if_flagged(self):
-        """`clip_grad_norm_(..., error_if_nonfinite=True)` semantics; the kernel skipped the update when the norm was non-finite."""
-        if self._flag_pending:
+    def _raise_if_flagged(self, wait=False):
+        """`clip_grad_norm_(..., error_if_nonfinite=True)` semantics without a per-step host sync: the kernel skips the
+        whole update when the norm is non-finite (state stays intact), and the flag is read from pinned memory as soon as
+        its copy has landed (`wait=True` blocks for it)."""
+        if self._flag_pending and (wait or self._flag_event.query()):
+            if wait:
+                self._flag_event.synchronize()
             self._flag_pending = False
-            norm, finite = self.norm_out.tolist()
+            norm, finite = self.norm_host.tolist()
             if finite == 0.0:
                 raise RuntimeError(f'The total norm for gradients is non-finite ({norm}), so it cannot be clipped.')
 
     def grad_norm(self):
         """pre-clip global gradient L2 norm of the last step (device sync)"""
         return float(self.norm_out[0].item())
+
+    def finish(self):
+        """drain the deferred non-finite check (call after the last step)"""
+        self._raise_if_flagged(wait=True)
 
 
 def clip_grad_norm_(model, max_norm=1.0, error_if_nonfinite=True):
