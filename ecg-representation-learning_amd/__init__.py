@@ -9,6 +9,7 @@ from .check_args import ca, CheckArg
 from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT
 from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
 from . import hip
+from . import ddp
 
 __all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'get_train_args', 'lr_multiplier',
-           'HipTrainStep', 'clip_grad_norm_', 'hip']
+           'HipTrainStep', 'clip_grad_norm_', 'hip', 'ddp']

@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 from .check_args import ca
 from . import hip
+from . import ddp
 
 
 def get_train_args(args=None, n_train=None):
@@ -110,9 +111,7 @@ class HipTrainStep:
 
     # -- gradient all-reduce (RCCL over xGMI): one collective over the flat gradient buffer
     def _allreduce(self, gflat):
-        if self.world == 1:
-            return
-        dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=self.pg)
+        ddp.allreduce_flat_(gflat, group=self.pg)
 
     def step(self, sample_values, labels):
         model = self.model

@@ -1,0 +1,94 @@
+"""CPU, world_size 2, gloo: the N > 1 path's logic -- contiguous equal shards, one SUM all-reduce over the flat gradient
+buffer, 1/world folded into the update, clip on the REDUCED gradient -- reproduces the single-process full-batch step.
+The per-rank compute here is the CPU oracle (the HIP kernels need a GPU); what is under test is ecg_..._amd.ddp + the
+flat layout, which are device-agnostic and are exactly what HipTrainStep calls on the GPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import Cfg, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import ecg_representation_learning_amd as E
+    from ecg_representation_learning_amd.engine import ParamLayout
+    from oracle import vit_oracle as O
+    torch.set_num_threads(2)
+    cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
+    torch.manual_seed(1234 + rank)                      # deliberately different init per rank ...
+    model = O.OracleEcgVit(config=cfg).train()
+    layout = ParamLayout([(n, tuple(p.shape)) for n, p in model.named_parameters()])
+    pflat = torch.zeros(layout.total)
+    for n, p in model.named_parameters():
+        layout.view(pflat, n).copy_(p.data)
+        p.data = layout.view(pflat, n)
+    E.ddp.broadcast_flat_(pflat, src=0)                 # ... made identical by one broadcast of the flat buffer
+    G = 8
+    x, y = O.synthetic_batch(G, length=400, seed=77)    # the GLOBAL batch, identical on every rank
+    lo, hi = E.ddp.shard_range(G, rank, world)
+    out = model(sample_values=x[lo:hi], labels=y[lo:hi])
+    out.loss.backward()
+    gflat = torch.zeros(layout.total)
+    for n, p in model.named_parameters():
+        layout.view(gflat, n).copy_(p.grad)
+    w = E.ddp.allreduce_flat_(gflat, bucket_elems=1000 if rank >= 0 else 0)   # bucketed variant
+    gflat /= w
+    norm = gflat.norm()
+    coef = torch.clamp(1.0 / (norm + 1e-6), max=1.0)
+    torch.save(dict(g=gflat * coef, norm=norm, loss=out.loss.detach(), p=pflat.clone(), seed=E.ddp.rank_seed(77, rank)),
+               os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in range(world))
+    assert torch.equal(r0['p'], r1['p'])                       # broadcast made the replicas identical
+    assert torch.allclose(r0['g'], r1['g'], rtol=0, atol=0)    # every rank holds the same reduced, clipped gradient
+    assert (r0['seed'], r1['seed']) == (77, 78)
+    # single-process full-batch reference
+    from ecg_representation_learning_amd.engine import ParamLayout
+    from oracle import vit_oracle as O
+    cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
+    torch.manual_seed(1234)
+    model = O.OracleEcgVit(config=cfg).train()
+    layout = ParamLayout([(n, tuple(p.shape)) for n, p in model.named_parameters()])
+    x, y = O.synthetic_batch(8, length=400, seed=77)
+    out = model(sample_values=x, labels=y)
+    out.loss.backward()
+    tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    g = torch.zeros(layout.total)
+    for n, p in model.named_parameters():
+        layout.view(g, n).copy_(p.grad)
+    assert abs(float(r0['norm']) - float(tn)) / float(tn) < 1e-5
+    assert float((r0['g'] - g).norm() / g.norm()) < 1e-5
+    assert abs(float(out.loss) - 0.5 * (float(r0['loss']) + float(r1['loss']))) < 1e-6   # mean of shard means
+
+
+def test_shard_range_contract():
+    import ecg_representation_learning_amd as E
+    assert [E.ddp.shard_range(4096, r, 8) for r in (0, 7)] == [(0, 512), (3584, 4096)]
+    with pytest.raises(ValueError):
+        E.ddp.shard_range(10, 0, 4)
+    g = torch.ones(5)
+    assert E.ddp.allreduce_flat_(g) == 1 and torch.equal(g, torch.ones(5))   # no process group: identity
