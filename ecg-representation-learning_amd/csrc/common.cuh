@@ -88,23 +88,48 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 }
 
 // ---- counter-based dropout mask: keep(seed, element) is a pure function, recomputed in backward ----
-__device__ __forceinline__ uint32_t mix32(uint64_t seed, uint64_t idx) {
-    uint64_t z = (idx + 0x9E3779B97F4A7C15ull) * 0xBF58476D1CE4E5B9ull ^ seed;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+// One 32-bit murmur-style hash per PAIR of consecutive elements, 16 random bits each (threshold = p * 2^16):
+// ~4 VALU ops per element instead of the ~40 of a 64-bit mixer (the FFN epilogues touch 4e8 elements per launch).
+__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint64_t idx) {
+    uint32_t h = (uint32_t)(idx >> 1) * 0x9E3779B1u + (uint32_t)seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
 }
 // returns the multiplier: 0 or 1/(1-p)
 __device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
-    return mix32(seed, idx) >= thresh ? inv_keep : 0.f;
+    const uint32_t h = pair_hash(seed, idx);
+    const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+    return r >= thresh ? inv_keep : 0.f;
+}
+// 8 consecutive elements starting at an EVEN index: 4 hashes
+__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint64_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = pair_hash(seed, idx0 + 2 * k);
+        v[2 * k] *= (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+        v[2 * k + 1] *= (h >> 16) >= thresh ? inv_keep : 0.f;
+    }
 }
 static inline uint32_t dropout_threshold(float p) {
     if (p <= 0.f) return 0u;
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    double t = (double)p * 65536.0 + 0.5;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
 }
+
+// ---- bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16's 2^-8), one exp + one rcp;
+//      GELU' reuses the same exponential (erf(x/sqrt2) is built on e^{-x^2/2} = sqrt(2 pi) * pdf) -----------------
+__device__ __forceinline__ void gelu_fast_parts(float x, float &cdf, float &pdf) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float ex = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * ex;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    pdf = 0.39894228040143267794f * ex;
+}
+__device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }
+__device__ __forceinline__ float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return c + x * p; }
 
 // ---- epilogue parameters shared by the f32 and bf16 GEMMs -------------------------------------
 struct EpiParams {

@@ -17,6 +17,7 @@
 // Block order: 1-D grid remapped so that the 8 XCDs each own a contiguous run of tiles, N fastest: the blocks
 //   sharing an activation row-panel run on one XCD's L2; the (small) weight matrix streams from L2/MALL.
 #include "common.cuh"
+#include <cstdlib>
 
 namespace {
 
@@ -208,16 +209,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ecgvit_gemm_desc d, E
                 for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
                 st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = gelu_erf(pre.get(k));
+                for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
             }
-            if (e.flags & ECGVIT_EPI_DROPOUT) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= dropout_mult(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)(n + k), e.drop_thresh, e.inv_keep);
-            }
+            if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep, v);
             if (e.flags & ECGVIT_EPI_GELU_BWD) {
                 const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] *= gelu_erf_grad(pre.get(k));
+                for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
             }
             if (e.flags & ECGVIT_EPI_RESIDUAL) {
                 const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);
@@ -282,11 +280,22 @@ inline int choose_splits(const ecgvit_gemm_desc *d, int ntile) {
 
 }  // namespace
 
+// large-shape variant (gemm_bf16_v2.hip)
+bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d);
+int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d);
+int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s);
+
+static bool use_v2() {
+    static const bool on = [] { const char *e = getenv("ECGVIT_GEMM_V2"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 extern "C" int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d) {
     if (d->dtype != ECGVIT_BF16 || d->layout != ECGVIT_GEMM_TN) return 0;
     const int ntile = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
     const int s = choose_splits(d, ntile);
-    return s > 1 ? (int64_t)s * d->M * d->N * 4 : 0;
+    const int64_t v1 = s > 1 ? (int64_t)s * d->M * d->N * 4 : 0;
+    return std::max(v1, ecgvit_gemm_bf16_v2_workspace(d));
 }
 
 int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
@@ -305,6 +314,7 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
+    if (use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_v2_launch(d, s);
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     SplitK sk;
     sk.splits = 1;

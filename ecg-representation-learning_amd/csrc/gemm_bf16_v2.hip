@@ -1,0 +1,562 @@
+// bf16 MFMA GEMM, large-shape variant: 256x256x64 block tile, 8 waves (2 x 4, wave tile 128 x 64 = 4x2 accumulators of
+// 32x32 -> 128 acc VGPRs), operands streamed HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging, no
+// ds_write), two 64-KiB stages, ONE raw s_barrier per K-tile with the next tile's DMA in flight behind the MFMAs.
+//
+// Why this shape (MI355X): per K-tile a wave issues 24 ds_read_b128 (16 A + 8 B fragments) for 32 MFMAs, i.e. 768 LDS
+// cycles per CU against 2048 MFMA cycles per SIMD pair -- the 128^2 register-staged kernel (gemm_bf16.hip) needs 1024 LDS
+// cycles (reads + ds_write staging) per 1024 MFMA cycles and is LDS-bound at ~22 % of peak.
+//
+// LDS images (the DMA destination is wave-uniform base + lane*16, so swizzles are applied to the per-lane SOURCE address):
+//   K-contiguous operand  [256 rows][64 k]   (128-B rows): 16-B chunk ^= (row>>1)&7        -> conflict-free ds_read_b128
+//   k-major operand       [64 k][256 mn]     (512-B rows): 16-B chunk ^= (k&3)<<2          -> the 4 k-rows of one
+//                         ds_read_b64_tr_b16 half-wave land on the 4 distinct 64-B quarters of the bank row
+// Out-of-range source chunks (M/N tails of k-major operands, K tails) are pointed at a 16-B zero word in device memory.
+// Epilogue: each wave drains its accumulators through a private 64 x 68 f32 LDS patch (two passes) and writes 128-B row
+// segments with bias / GELU / GELU' / dropout / residual applied in f32 (same semantics as gemm_bf16.hip).
+#include "common.cuh"
+#include <cstdlib>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int TILE_BYTES = 32768, STAGE_BYTES = 65536;
+constexpr int CS_LD = 68, CS_WAVE_BYTES = 64 * CS_LD * 4;  // 17408
+constexpr int LDS_BYTES = 163840;                          // all of LDS: SCHED 3 rings (3 A + 2 B tiles); epilogue patches need 139264
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// issue this wave's 4 DMA instructions (4 KiB) of one operand tile
+template <bool KC, int I0 = 0, int I1 = 4>
+__device__ __forceinline__ void dma_tile(const bf16_t *__restrict__ P, int64_t ld, int mn0, int k0, int MN, int K, char *tile,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int i = I0; i < I1; ++i) {
+        const int j = wave * 4 + i;
+        const bf16_t *src;
+        if constexpr (KC) {
+            const int r = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int row = mn0 + r;
+            row = row < MN ? row : MN - 1;
+            const int k = k0 + c * 8;
+            src = k < K ? P + (int64_t)row * ld + k : reinterpret_cast<const bf16_t *>(g_zero16);
+        } else {
+            const int kr = j * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            const int k = k0 + kr, mn = mn0 + c * 8;
+            src = (k < K && mn < MN) ? P + (int64_t)k * ld + mn : reinterpret_cast<const bf16_t *>(g_zero16);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + j * 1024), 16, 0, 0);
+    }
+}
+
+// fragment: element j of lane (r = lane&31, h = lane>>5) = X[mn = base + r][k = 16*ks + 8h + j]
+template <bool KC> __device__ __forceinline__ bf16x8 frag(const char *tile, int mn_base, int ks, int lane) {
+    if constexpr (KC) {
+        const int row = mn_base + (lane & 31);
+        return *reinterpret_cast<const bf16x8 *>(tile + row * 128 + (((ks * 2 + (lane >> 5)) ^ ((row >> 1) & 7)) << 4));
+    } else {
+        const int g = lane >> 4, i = lane & 15;
+        const int colb = (mn_base + (g & 1) * 16 + (i & 3) * 4) * 2;
+        const int k = ks * 16 + (g >> 1) * 8 + (i >> 2);  // k and k+4 share (k&3)
+        const char *p = tile + k * 512 + (colb ^ ((k & 3) << 6));
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p + 4 * 512));
+        bf16x8 o;
+        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
+        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
+        return o;
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+struct SplitK2 {
+    int splits, k_per_split;
+    float *slabs;
+    int ablate;  // diagnostics only (ECGVIT_GEMM_ABLATE): 1 = no DMA after the prologue, 2 = no MFMA; results are garbage
+};
+
+// Drain one wave's 128 x 64 accumulator block through its private LDS patch (two 64-row passes) and store 128-B row segments.
+template <typename TO>
+__device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, const ecgvit_gemm_desc &d, const EpiParams &e,
+                                               const SplitK2 &sk, int split, int m0, int n0, int wave, int lane) {
+    const int M = d.M, N = d.N;
+    const int wm = wave >> 2, wn = wave & 3;
+    float *Cs = reinterpret_cast<float *>(smem + wave * CS_WAVE_BYTES);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int cc = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + cc;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Cs[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS_LD + j * 32 + lr] = acc[hh * 2 + ii][j][r];
+        // same-wave LDS ops execute in order: the reads below see the writes above
+#pragma unroll 2
+        for (int p = 0; p < 8; ++p) {
+            const int rr = p * 8 + (lane >> 3);
+            const int64_t m = m0 + wm * 128 + hh * 64 + rr;
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(&Cs[rr * CS_LD + cc]);
+            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(&Cs[rr * CS_LD + cc + 4]);
+            if (m >= M || n >= N) continue;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = c0[k]; v[4 + k] = c1[k]; }
+            if (sk.splits > 1) {
+                float *o = sk.slabs + ((int64_t)split * M + m) * N + n;
+                *reinterpret_cast<f32x4 *>(o) = c0;
+                *reinterpret_cast<f32x4 *>(o + 4) = c1;
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
+            if (e.flags & ECGVIT_EPI_BIAS) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(e.bias + n), b1 = *reinterpret_cast<const f32x4 *>(e.bias + n + 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+            }
+            if constexpr (sizeof(TO) == 2) {
+                if (e.flags & ECGVIT_EPI_GELU) {
+                    Vec16<bf16_t> pre;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
+                    st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
+                }
+                if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep, v);
+                if (e.flags & ECGVIT_EPI_GELU_BWD) {
+                    const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
+                }
+                if (e.flags & ECGVIT_EPI_RESIDUAL) {
+                    const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += res.get(k);
+                }
+                bf16_t *o = reinterpret_cast<bf16_t *>(d.C) + m * d.ldc + n;
+                if (e.flags & ECGVIT_EPI_ACCUM) {
+                    const Vec16<bf16_t> old = ld16(o);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] += old.get(k);
+                }
+                Vec16<bf16_t> out;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) out.set(k, v[k]);
+                st16(o, out);
+            } else {
+                float *o = reinterpret_cast<float *>(d.C) + m * d.ldc + n;
+                if (e.flags & ECGVIT_EPI_ACCUM) {
+                    const f32x4 o0 = *reinterpret_cast<const f32x4 *>(o), o1 = *reinterpret_cast<const f32x4 *>(o + 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { v[k] += o0[k]; v[4 + k] += o1[k]; }
+                }
+                f32x4 w0, w1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { w0[k] = v[k]; w1[k] = v[4 + k]; }
+                *reinterpret_cast<f32x4 *>(o) = w0;
+                *reinterpret_cast<f32x4 *>(o + 4) = w1;
+            }
+        }
+    }
+}
+
+// SCHED 0: all 8 waves in lockstep (read fragments, then MFMA).
+// SCHED 1: ping-pong -- waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave issues its 8 MFMAs of a
+//          16-deep k-step while its partner reads the next fragments / issues DMA; two raw barriers per k-step.
+template <bool A_KC, bool B_KC, typename TO, int SCHED>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+    const int ntile = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntile;
+    const int tid = xcd_remap(blockIdx.x - split * ntile, ntile);
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = d.M, N = d.N;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const bf16_t *A = reinterpret_cast<const bf16_t *>(d.A);
+    const bf16_t *B = reinterpret_cast<const bf16_t *>(d.B);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    if (nk > 0) {
+        dma_tile<A_KC>(A, d.lda, m0, kbeg, M, kend, smem, wave, lane);
+        dma_tile<B_KC>(B, d.ldb, n0, kbeg, N, kend, smem + (SCHED == 3 ? 3 * TILE_BYTES : TILE_BYTES), wave, lane);
+    }
+    if constexpr (SCHED == 0) {
+        for (int kt = 0; kt < nk; ++kt) {
+            // tile kt has landed (only it is in flight); the barrier also says every wave finished reading the other stage
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) {
+                char *ns = smem + ((kt + 1) & 1) * STAGE_BYTES;
+                dma_tile<A_KC>(A, d.lda, m0, kbeg + (kt + 1) * BK, M, kend, ns, wave, lane);
+                dma_tile<B_KC>(B, d.ldb, n0, kbeg + (kt + 1) * BK, N, kend, ns + TILE_BYTES, wave, lane);
+            }
+            const char *sa = smem + (kt & 1) * STAGE_BYTES;
+            const char *sb = sa + TILE_BYTES;
+            // software pipeline over the 4 k-steps: fragments of step ks+1 are in flight behind the 8 MFMAs of step ks
+            bf16x8 a[2][4], b[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j] = frag<B_KC>(sb, wn * 64 + j * 32, 0, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = frag<A_KC>(sa, wm * 128 + i * 32, 0, lane);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < BK / 16) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[nxt][j] = frag<B_KC>(sb, wn * 64 + j * 32, ks + 1, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[nxt][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks + 1, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if constexpr (SCHED == 3) {
+        // Asymmetric rings: A (the streamed activation panel, compulsory HBM misses) gets THREE 32-KiB slots and is prefetched
+        // two K-tiles ahead; B (weights, L2/MALL-resident) gets two slots, one tile ahead.  96 KiB in flight instead of 64.
+        // Issue order per iteration is B(kt+1) then A(kt+2), so at the top of iteration kt only A(kt+1) may still fly: vmcnt(4).
+        char *sA = smem, *sB = smem + 3 * TILE_BYTES;
+        if (nk > 1) dma_tile<A_KC>(A, d.lda, m0, kbeg + BK, M, kend, sA + TILE_BYTES, wave, lane);   // A(1)
+        int sa_i = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) dma_tile<B_KC>(B, d.ldb, n0, kbeg + (kt + 1) * BK, N, kend, sB + ((kt + 1) & 1) * TILE_BYTES, wave, lane);
+            if (kt + 2 < nk) {
+                int s2 = sa_i + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
+                dma_tile<A_KC>(A, d.lda, m0, kbeg + (kt + 2) * BK, M, kend, sA + s2 * TILE_BYTES, wave, lane);
+            } else if (kt + 1 < nk) {
+                // keep the vmcnt arithmetic uniform on the second-to-last tile: nothing to prefetch, so wait for everything next time
+            }
+            const char *sa = sA + sa_i * TILE_BYTES;
+            const char *sb = sB + (kt & 1) * TILE_BYTES;
+            bf16x8 a[2][4], b[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j] = frag<B_KC>(sb, wn * 64 + j * 32, 0, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[0][i] = frag<A_KC>(sa, wm * 128 + i * 32, 0, lane);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int cur = ks & 1, nxt = cur ^ 1;
+                if (ks + 1 < BK / 16) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[nxt][j] = frag<B_KC>(sb, wn * 64 + j * 32, ks + 1, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[nxt][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks + 1, lane);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sa_i = sa_i + 1 == 3 ? 0 : sa_i + 1;
+        }
+    } else {
+        const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // tile 0 visible to everyone
+        if (late) __builtin_amdgcn_s_barrier();    // stagger: waves 4-7 run one barrier behind
+        for (int kt = 0; kt < nk; ++kt) {
+            const char *sa = smem + (kt & 1) * STAGE_BYTES;
+            const char *sb = sa + TILE_BYTES;
+            char *ns = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            const bool more = kt + 1 < nk;
+            const int k1 = kbeg + (kt + 1) * BK;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                // ---- R phase: this wave reads its fragments for (kt, ks) and feeds the DMA queue; its SIMD partner is in M
+                bf16x8 a[4], b[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = frag<B_KC>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
+                if (more && !(sk.ablate & 1)) {  // tile kt+1 -> other stage: 3 + 3 + 2 DMA instructions over the first three k-steps
+                    if (ks == 0) {
+                        dma_tile<A_KC, 0, 3>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
+                    } else if (ks == 1) {
+                        dma_tile<A_KC, 3, 4>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
+                        dma_tile<B_KC, 0, 2>(B, d.ldb, n0, k1, N, kend, ns + TILE_BYTES, wave, lane);
+                    } else if (ks == 2) {
+                        dma_tile<B_KC, 2, 4>(B, d.ldb, n0, k1, N, kend, ns + TILE_BYTES, wave, lane);
+                    }
+                }
+                if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my share of tile kt+1 has landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M phase
+                if (sk.ablate & 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(a[i]));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(b[j]));
+                } else {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!late) __builtin_amdgcn_s_barrier();   // re-align the two halves
+    }
+    // every wave is done with the staging buffers before they are reused as epilogue patches
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_store<TO>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ring variant (SCHED 2): same 256x256 tile / 8 waves / epilogue, but BK = 32 and a FIVE-stage LDS ring (5 x 32 KiB = all
+// 160 KiB): four K-stages of DMA stay in flight behind the stage being multiplied.  The 2-stage kernels above wait on
+// HBM-miss latency once per K-tile (measured: 2.15 us per 64-deep tile vs 0.9 us of MFMA time); a prefetch distance of four
+// stages (~2 us of MFMA work) covers it.  One raw barrier per stage; counted vmcnt (12 = three younger stages in flight).
+//   K-contiguous tile  [256 rows][32 k]  (64-B rows): 16-B chunk ^= (row>>2)&3
+//   k-major tile       [32 k][256 mn]    (512-B rows): 16-B chunk ^= (k&3)<<2   (as above)
+constexpr int RBK = 32, RSTAGES = 5, RTILE = 16384, RSTAGE = 32768;
+constexpr int RING_LDS = RSTAGES * RSTAGE;  // 163840
+
+template <bool KC>
+__device__ __forceinline__ void ring_dma(const bf16_t *__restrict__ P, int64_t ld, int mn0, int k0, int MN, int K, char *tile,
+                                         int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;  // 16 x 1 KiB pieces per tile
+        const bf16_t *src;
+        if constexpr (KC) {
+            const int r = j * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            int row = mn0 + r;
+            row = row < MN ? row : MN - 1;
+            const int k = k0 + c * 8;
+            src = k < K ? P + (int64_t)row * ld + k : reinterpret_cast<const bf16_t *>(g_zero16);
+        } else {
+            const int kr = j * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            const int k = k0 + kr, mn = mn0 + c * 8;
+            src = (k < K && mn < MN) ? P + (int64_t)k * ld + mn : reinterpret_cast<const bf16_t *>(g_zero16);
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile + j * 1024), 16, 0, 0);
+    }
+}
+
+template <bool KC> __device__ __forceinline__ bf16x8 ring_frag(const char *tile, int mn_base, int ks, int lane) {
+    if constexpr (KC) {
+        const int row = mn_base + (lane & 31);
+        return *reinterpret_cast<const bf16x8 *>(tile + row * 64 + (((ks * 2 + (lane >> 5)) ^ ((row >> 2) & 3)) << 4));
+    } else {
+        return frag<false>(tile, mn_base, ks, lane);  // same [k][256] image, 32 rows
+    }
+}
+
+template <bool A_KC, bool B_KC, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[RING_LDS];
+    const int ntile = tiles_m * tiles_n;
+    const int split = blockIdx.x / ntile;
+    const int tid = xcd_remap(blockIdx.x - split * ntile, ntile);
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = d.M, N = d.N;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const bf16_t *A = reinterpret_cast<const bf16_t *>(d.A);
+    const bf16_t *B = reinterpret_cast<const bf16_t *>(d.B);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (kend - kbeg + RBK - 1) / RBK;
+    // prologue: stages 0..3 in flight (empty DMA slots are issued too, so the vmcnt arithmetic below is uniform)
+#pragma unroll
+    for (int t = 0; t < RSTAGES - 1; ++t) {
+        const int k0 = kbeg + t * RBK;   // k0 >= kend -> every lane reads the zero word
+        ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + t * RSTAGE, wave, lane);
+        ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + t * RSTAGE + RTILE, wave, lane);
+    }
+    int slot = 0;
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // my pieces of stage t have landed (3 younger stages may fly)
+        __builtin_amdgcn_s_barrier();                         // stage t visible; everyone is done with stage t-1
+        {
+            const int k0 = kbeg + (t + RSTAGES - 1) * RBK;
+            int ps = slot + RSTAGES - 1;
+            ps = ps >= RSTAGES ? ps - RSTAGES : ps;           // slot of stage t-1 == slot of stage t+4
+            ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + ps * RSTAGE, wave, lane);
+            ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + ps * RSTAGE + RTILE, wave, lane);
+        }
+        const char *sa = smem + slot * RSTAGE;
+        const char *sb = sa + RTILE;
+        bf16x8 a[2][4], b[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[ks][j] = ring_frag<B_KC>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[ks][i] = ring_frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == RSTAGES ? 0 : slot + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_store<TO>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
+                                                             TO *__restrict__ C, int64_t ldc, EpiParams e) {
+    const int64_t nv = MN / 4;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = *reinterpret_cast<const f32x4 *>(slabs + i * 4);
+        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(slabs + (int64_t)k * MN + i * 4);
+        const int64_t m = (i * 4) / N;
+        const int n = (int)((i * 4) - m * N);
+        TO *o = C + m * ldc + n;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = s[k] * e.alpha;
+            if (e.flags & ECGVIT_EPI_BIAS) v += e.bias[n + k];
+            if (e.flags & ECGVIT_EPI_ACCUM) v += to_f32<TO>(o[k]);
+            o[k] = from_f32<TO>(v);
+        }
+    }
+}
+
+inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
+    if (d->layout != ECGVIT_GEMM_TN) return 1;
+    const int ksteps = (d->K + BK - 1) / BK;
+    int s = 256 / ntile;                         // one 139-KiB block per CU: fill ONE round of the 256 CUs, never 2.1
+    if (s < 1) s = 1;
+    s = std::min(s, std::max(1, ksteps / 16));   // keep >= 16 K-steps per split
+    return std::max(1, std::min(s, 64));
+}
+
+}  // namespace
+
+bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d) {
+    // large activations-by-weights products only; small / ragged problems stay on the 128^2 kernel
+    if (d->layout == ECGVIT_GEMM_TN) return d->K >= 4096 && d->M >= 128 && d->N >= 128;
+    return d->M >= 2048 && d->N >= 256;
+}
+
+int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d) {
+    if (d->layout != ECGVIT_GEMM_TN) return 0;
+    const int ntile = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+    const int s = choose_splits2(d, ntile);
+    return s > 1 ? (int64_t)s * d->M * d->N * 4 : 0;
+}
+
+// argument validation is done by the caller (ecgvit_gemm_bf16_launch)
+int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
+    const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    SplitK2 sk;
+    sk.splits = 1;
+    sk.slabs = nullptr;
+    sk.k_per_split = ((d->K + BK - 1) / BK) * BK;
+    static const int ablate = [] { const char *e = getenv("ECGVIT_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    sk.ablate = ablate;
+    if (d->workspace && d->layout == ECGVIT_GEMM_TN) {
+        int sp = choose_splits2(d, ntile);
+        while (sp > 1 && (int64_t)sp * d->M * d->N * 4 > d->workspace_bytes) --sp;
+        if (sp > 1 && ((int64_t)d->M * d->N) % 4 == 0 && !(d->epilogue & ~(ECGVIT_EPI_BIAS | ECGVIT_EPI_ACCUM))) {
+            const int ksteps = (d->K + BK - 1) / BK;
+            sk.splits = sp;
+            sk.k_per_split = ((ksteps + sp - 1) / sp) * BK;
+            sk.slabs = reinterpret_cast<float *>(d->workspace);
+        }
+    }
+    EpiParams e = make_epi(d);
+    dim3 grid((unsigned)(ntile * sk.splits)), block(512);
+    static const int sched = [] { const char *e = getenv("ECGVIT_GEMM_SCHED"); return e ? atoi(e) : 1; }();
+#define LAUNCH(AK, BKC, TO)                                                                                              \
+    do {                                                                                                                   \
+        if (sched == 2) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (sched == 0) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 0>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (sched == 3) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 3>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 1>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);  \
+    } while (0)
+    const bool obf = d->out_dtype == ECGVIT_BF16;
+    switch (d->layout) {
+        case ECGVIT_GEMM_NT: if (obf) LAUNCH(true, true, bf16_t); else LAUNCH(true, true, float); break;
+        case ECGVIT_GEMM_NN: if (obf) LAUNCH(true, false, bf16_t); else LAUNCH(true, false, float); break;
+        case ECGVIT_GEMM_TN: if (obf) LAUNCH(false, false, bf16_t); else LAUNCH(false, false, float); break;
+        default: return ECGVIT_EINVAL;
+    }
+#undef LAUNCH
+    ECGVIT_CHECK_LAUNCH();
+    if (sk.splits > 1) {
+        const int64_t MN = (int64_t)d->M * d->N;
+        const int g = (int)std::min<int64_t>((MN / 4 + 255) / 256, 2048);
+        if (obf) hipLaunchKernelGGL(splitk_reduce2_kernel<bf16_t>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (bf16_t *)d->C, d->ldc, e);
+        else hipLaunchKernelGGL(splitk_reduce2_kernel<float>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (float *)d->C, d->ldc, e);
+        ECGVIT_CHECK_LAUNCH();
+    }
+    return ECGVIT_OK;
+}

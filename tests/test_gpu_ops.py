@@ -507,3 +507,30 @@ def test_masked_objective_ops(dtype):
     diff = pred.double() - tgt.double()
     assert abs(float(loss) - float(diff.abs().mean())) < 1e-5
     assert rel_err(dpred, torch.sign(diff) / diff.numel()) < (1e-6 if dtype == F32 else 4e-3)
+
+
+# ------------------------------------------------------------------------------------------------------ large-shape GEMM variant
+@pytest.mark.parametrize('layout,shape', [
+    (hip.GEMM_NT, (4133, 768, 768)), (hip.GEMM_NT, (2048, 264, 240)), (hip.GEMM_NT, (2500, 3072, 768)),
+    (hip.GEMM_NN, (4133, 768, 2304)), (hip.GEMM_NN, (2051, 520, 768)),
+    (hip.GEMM_TN, (768, 3072, 9001)), (hip.GEMM_TN, (2304, 768, 4099)), (hip.GEMM_TN, (768, 240, 5000)),
+])
+def test_gemm_bf16_large_shapes(layout, shape):
+    """shapes that dispatch to the 256x256 LDS-DMA kernel (gemm_bf16_v2.hip): ragged M, N and K tails, split-K wgrad"""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = _operands(layout, M, N, K, BF16, g)
+    ref = _gemm_ref(layout, A.float(), B.float())
+    if layout == hip.GEMM_TN:
+        ws = torch.empty(max(16, hip.gemm_workspace_bytes(layout, BF16, M, N, K)), dtype=torch.uint8, device='cuda')
+        C = torch.full((M, N), float('nan'), device='cuda')
+        hip.gemm(layout, dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, workspace=ws)
+        assert rel_err(C, ref) < 2e-5
+    else:
+        C = torch.full((M, N), float('nan'), device='cuda', dtype=BF16)
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g).to(BF16)
+        hip.gemm(layout, dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, epilogue=hip.EPI_BIAS | hip.EPI_RESIDUAL, bias=dev(bias),
+                 residual=dev(res), ldr=N)
+        assert torch.isfinite(C.float()).all()
+        assert rel_err(C, ref + bias.double() + res.double()) < 4e-3
