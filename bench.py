@@ -86,7 +86,7 @@ class GemmProbe:
                     flops_per_launch=self.flops / n)
 
 
-def cpu_baseline(conf, seconds_budget=25.0):
+def cpu_baseline(conf, seconds_budget=25.0, masked=False):
     """the CPU oracle (torch eager f32 restatement of the reference step) on the host cores, bounded sample (~seconds_budget)"""
     from oracle import vit_oracle as O
     try:
@@ -96,8 +96,27 @@ def cpu_baseline(conf, seconds_budget=25.0):
     flops_rec = O.train_flops_per_record(conf)
     torch.manual_seed(77)
     model = O.OracleEcgVit(config=conf).train()
-    tr = O.OracleTrainer(model, n_step=100)
-    x1, y1 = O.synthetic_batch(1, length=conf.max_signal_length, seed=77)
+    n_patch = conf.max_signal_length // conf.patch_size
+    if masked:
+        mm = O.OracleMaskedEcgVit(model).train()
+
+        class _Adapter(torch.nn.Module):   # OracleTrainer calls model(sample_values=, labels=): labels carry the mask indices
+            def __init__(self):
+                super().__init__()
+                self.mm = mm
+
+            def forward(self, sample_values, labels):
+                return self.mm(sample_values, labels)
+        tr = O.OracleTrainer(_Adapter(), n_step=100)
+    else:
+        tr = O.OracleTrainer(model, n_step=100)
+
+    def batch_of(b):
+        xx, yy = O.synthetic_batch(b, length=conf.max_signal_length, seed=77)
+        if masked:
+            yy = torch.stack([torch.randperm(n_patch)[:n_patch // 2] for _ in range(b)]).int()
+        return xx, yy
+    x1, y1 = batch_of(1)
     # pick the thread count that runs a 1-record step fastest (torch eager does not scale to hundreds of threads)
     best = None
     for t in sorted({min(avail, c) for c in (16, 32, 64)}):
@@ -111,7 +130,7 @@ def cpu_baseline(conf, seconds_budget=25.0):
     cores, t1 = best
     torch.set_num_threads(cores)
     b = max(1, min(32, int(seconds_budget * 0.5 / 2 / max(t1, 1e-3))))   # two timed steps in about half the budget
-    x, y = O.synthetic_batch(b, length=conf.max_signal_length, seed=77)
+    x, y = batch_of(b)
     tr.step(x, y)  # warm-up at the timed shape
     t0 = time.perf_counter()
     n = 0
@@ -136,6 +155,8 @@ def main():
     ap.add_argument('--patch', type=int, default=20)
     ap.add_argument('--length', type=int, default=5000)
     ap.add_argument('--dropout', type=float, default=None, help='override (default: reference config default 0.1)')
+    ap.add_argument('--objective', default='supervised', choices=['supervised', 'masked'],
+                    help="'supervised' = the reference's BCE step; 'masked' = the build's SimMIM-style masked pre-train step (seq = n patches, no CLS)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
     args = ap.parse_args()
@@ -159,11 +180,17 @@ def main():
     batch = args.batch or batch
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     torch.manual_seed(77)  # identical initial weights on every rank
-    model = E.EcgVit(config=conf, compute_dtype=dtype).to(dev).train()
+    model = E.EcgVit(config=conf, compute_dtype=dtype)
+    if args.objective == 'masked':
+        model = E.MaskedEcgVit(model, mask_ratio=0.5)
+    model = model.to(dev).train()
     x, y = O.synthetic_batch(batch, length=conf.max_signal_length, seed=77 + rank)
     x, y = x.to(dev), y.to(dev)
+    if args.objective == 'masked':
+        y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank)).to(dev)   # (B, m) int32
     n_total = args.steps + args.warmup
     step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total))
+    run_step = step.step_masked if args.objective == 'masked' else step.step
 
     probe = None
     if not args.no_probe and dtype == torch.bfloat16:
@@ -177,13 +204,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step.step(x, y)
+        run_step(x, y)
     sync()
     if probe:
         probe.enabled = rank == 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = step.step(x, y)
+        loss, _ = run_step(x, y)
     sync()
     dt = time.perf_counter() - t0
     if probe:
@@ -206,10 +233,11 @@ def main():
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {
-                'workload': f'EcgVit-{args.config} supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW'
+                'workload': f'EcgVit-{args.config} ' + ('masked-patch pre-train step (SimMIM-style, 50 % of patches masked, L1 recon; fwd+loss+bwd+clip+AdamW'
+                            if args.objective == 'masked' else 'supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW') + (
                             f'{"+RCCL all-reduce" if world > 1 else ""}), dropout {conf.hidden_dropout_prob}, '
                             f'{batch} records/GPU x 12 leads x {conf.max_signal_length} samples, patch {conf.patch_size} '
-                            f'({conf.max_signal_length // conf.patch_size + 1} tokens), random-init weights, inputs resident in HBM',
+                            f'({conf.max_signal_length // conf.patch_size + (0 if args.objective == "masked" else 1)} tokens), random-init weights, inputs resident in HBM'),
                 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
                 'hidden': conf.hidden_size, 'layers': conf.num_hidden_layers, 'heads': conf.num_attention_heads,
             },
@@ -227,7 +255,7 @@ def main():
                     'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
                 }
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(conf)
+            out['cpu_baseline'] = cpu_baseline(conf, masked=args.objective == 'masked')
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -6,10 +6,10 @@ ModelOutput(loss, logits)` / train-step surface, executed by hand-written HIP ke
 fails loudly when the HIP library is absent (no CPU / eager fallback by design).
 """
 from .check_args import ca, CheckArg
-from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT
+from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT, MaskedEcgVit
 from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
 from . import hip
 from . import ddp
 
-__all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'get_train_args', 'lr_multiplier',
+__all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'get_train_args', 'lr_multiplier',
            'HipTrainStep', 'clip_grad_norm_', 'hip', 'ddp']

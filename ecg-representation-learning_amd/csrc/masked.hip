@@ -30,6 +30,39 @@ __global__ __launch_bounds__(256) void mask_embed_kernel(const T *__restrict__ t
     }
 }
 
+// backward of mask_embed: dtok = dX where NOT masked (else 0); dmasked = dX where masked (else 0) -> its column sum is the
+// mask-token gradient; dpos[1 + p] = sum_b dX[b*n + p]   (dpos row 0 = CLS slot, untouched by the masked trunk: zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_embed_bwd_kernel(const T *__restrict__ dX, const uint8_t *__restrict__ flag,
+                                                             T *__restrict__ dtok, T *__restrict__ dmasked,
+                                                             float *__restrict__ dpos, int B, int n, int d) {
+    constexpr int VN = Vec16<T>::N;
+    const int dv = d / VN;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * dv) return;
+    const int p = i / dv, c0 = (i - p * dv) * VN;
+    float acc[VN];
+#pragma unroll
+    for (int k = 0; k < VN; ++k) acc[k] = 0.f;
+    Vec16<T> zero;
+#pragma unroll
+    for (int k = 0; k < VN; ++k) zero.set(k, 0.f);
+    for (int b = 0; b < B; ++b) {
+        const int64_t row = (int64_t)b * n + p;
+        const Vec16<T> v = ld16(dX + row * d + c0);
+#pragma unroll
+        for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
+        const bool mk = flag[row] != 0;
+        st16(dtok + row * d + c0, mk ? zero : v);
+        st16(dmasked + row * d + c0, mk ? v : zero);
+    }
+#pragma unroll
+    for (int k = 0; k < VN; ++k) {
+        dpos[(int64_t)(1 + p) * d + c0 + k] = acc[k];
+        if (p == 0) dpos[c0 + k] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void mark_mask_kernel(const int32_t *__restrict__ idx, uint8_t *__restrict__ flag, int B, int n, int m) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * m) return;
@@ -95,6 +128,20 @@ int ecgvit_mask_embed_finish(const void *tok, const float *mask_token, const flo
         hipLaunchKernelGGL(mask_embed_kernel<float>, dim3(grid_ew(rows * d / 4)), dim3(256), 0, s, (const float *)tok, mask_token, pos, (const uint8_t *)flag_ws, (float *)X, rows, n, d);
     else if (dtype == ECGVIT_BF16)
         hipLaunchKernelGGL(mask_embed_kernel<bf16_t>, dim3(grid_ew(rows * d / 8)), dim3(256), 0, s, (const bf16_t *)tok, mask_token, pos, (const uint8_t *)flag_ws, (bf16_t *)X, rows, n, d);
+    else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_mask_embed_bwd(const void *dX, const void *flag_ws, void *dtok, void *dmasked, float *dpos, int B, int n, int d,
+                          int dtype, void *stream) {
+    if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0 || !flag_ws) return ECGVIT_EINVAL;
+    const int work = n * (d / (dtype == ECGVIT_F32 ? 4 : 8));
+    const int grid = (work + 255) / 256;
+    if (dtype == ECGVIT_F32)
+        hipLaunchKernelGGL(mask_embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)dX, (const uint8_t *)flag_ws, (float *)dtok, (float *)dmasked, dpos, B, n, d);
+    else if (dtype == ECGVIT_BF16)
+        hipLaunchKernelGGL(mask_embed_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)dX, (const uint8_t *)flag_ws, (bf16_t *)dtok, (bf16_t *)dmasked, dpos, B, n, d);
     else return ECGVIT_EINVAL;
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;

@@ -206,8 +206,8 @@ class _EcgVitFunction(torch.autograd.Function):
         elif glogits is not None:
             eng.backward(glogits=glogits.contiguous().float())
         else:
-            return (None,) * (5 + len(model._param_list))
-        grads = tuple(model._layout.view(model._gflat, n) for n in model._param_names)
+            return (None,) * (5 + len(model._own_list))
+        grads = tuple(model._layout.view(model._gflat, n) for n in model._own_names)
         return (None, None, None, None, None) + grads
 
 
@@ -248,9 +248,17 @@ class EcgVit(nn.Module):
         self._eng = None
         self._pflat = self._gflat = self._wlow = None
         self._wlow_version = -1
-        self._param_names = [n for n, _ in self.named_parameters()]
-        self._param_list = [p for _, p in self.named_parameters()]
-        self._layout = ParamLayout([(n, tuple(p.shape)) for n, p in self.named_parameters()])
+        self._own_names = [n for n, _ in self.named_parameters()]
+        self._own_list = [p for _, p in self.named_parameters()]
+        self._param_names, self._param_list = list(self._own_names), list(self._own_list)  # + attached extras (pre-train head)
+        self._layout = ParamLayout([(n, tuple(p.shape)) for n, p in zip(self._param_names, self._param_list)])
+        self._flatten()
+
+    def _attach_extra(self, named_params):
+        """append parameters owned by a wrapper (the masked pre-train head) to the flat HBM layout"""
+        self._param_names = list(self._own_names) + [n for n, _ in named_params]
+        self._param_list = list(self._own_list) + [p for _, p in named_params]
+        self._layout = ParamLayout([(n, tuple(p.shape)) for n, p in zip(self._param_names, self._param_list)])
         self._flatten()
 
     # ------------------------------------------------------------------ reference surface
@@ -275,7 +283,7 @@ class EcgVit(nn.Module):
             y = labels.contiguous().float()
             if self.loss_weight:  # reference :144-147: per-element weight looked up by the label value
                 w = torch.tensor(self.loss_weight, device=y.device, dtype=torch.float32)[y.long()].contiguous()
-        loss, logits = _EcgVitFunction.apply(self, x, y, w, self._loss_reduction, *self._param_list)
+        loss, logits = _EcgVitFunction.apply(self, x, y, w, self._loss_reduction, *self._own_list)
         return ModelOutput(loss=loss if labels is not None else None, logits=logits)
 
     # ------------------------------------------------------------------ flat HBM layout of the parameters
@@ -354,3 +362,69 @@ class EcgVit(nn.Module):
 
     def attention_probs(self, layer):
         return self._engine().attention_probs(layer).clone()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# masked pre-train objective -- NOT in the reference: the build's own SimMIM-style definition
+# ----------------------------------------------------------------------------------------------------------
+class _MaskedFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wrapper, x, idx, *params):
+        enc = wrapper.encoder
+        eng = enc._engine()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (enc.training and enc._has_dropout) else 0
+        pred, loss = eng.forward_masked(x, idx, training=enc.training, seed=seed)
+        enc._fwd_id += 1
+        ctx.wrapper, ctx.fwd_id = wrapper, enc._fwd_id
+        ctx.set_materialize_grads(False)
+        B, m = idx.shape
+        return loss.clone().reshape(()), pred.float().view(B, m, -1).clone()
+
+    @staticmethod
+    def backward(ctx, gloss, gpred):
+        enc = ctx.wrapper.encoder
+        if ctx.fwd_id != enc._fwd_id:
+            raise RuntimeError('MaskedEcgVit: a later forward overwrote the activations this backward needs')
+        if gpred is not None:
+            raise NotImplementedError('gradients through the reconstruction output')
+        if gloss is None:
+            return (None,) * (3 + len(enc._param_list))
+        enc._engine().backward_masked(gscalar=gloss.contiguous().float().reshape(1))
+        return (None, None, None) + tuple(enc._layout.view(enc._gflat, n) for n in enc._param_names)
+
+
+class MaskedEcgVit(nn.Module):
+    """
+    Self-supervised masked-patch pre-training around an `EcgVit` encoder (shares all encoder weights):
+      patches (B, n, C*P) --Linear--> tokens ; tokens[b, idx[b, :]] <- mask_token ; += pos_embedding[:, 1:n+1] ;
+      transformer trunk on the n tokens (no CLS) ; rows idx --Linear(d, C*P)--> reconstruction ;
+      loss = mean |reconstruction - raw masked patches|.
+    `mask_idx` (B, m) int32: distinct patch indices per record, generated on the host (`random_mask_indices`) so the
+    integer index handling is bit-exact and reproducible.  forward -> ModelOutput(loss, logits=(B, m, C*P) reconstruction).
+    Extra state_dict keys (not part of the reference checkpoint): `mask_token`, `to_pixels.{weight,bias}`.
+    """
+
+    def __init__(self, encoder: EcgVit, mask_ratio: float = 0.5):
+        super().__init__()
+        self.encoder = encoder
+        c = encoder.config
+        d, cp = c.hidden_size, c.num_channels * c.patch_size
+        self.mask_ratio = mask_ratio
+        self.n_patch = c.max_signal_length // c.patch_size
+        self.n_mask = max(1, int(mask_ratio * self.n_patch))
+        self.mask_token = nn.Parameter(torch.randn(d))
+        self.to_pixels = nn.Linear(d, cp)
+        encoder._attach_extra([('pretrain.mask_token', self.mask_token), ('pretrain.to_pixels.weight', self.to_pixels.weight),
+                               ('pretrain.to_pixels.bias', self.to_pixels.bias)])
+
+    def random_mask_indices(self, batch, generator=None):
+        """(B, m) int32 on the host: per record, the first m entries of a random permutation of the n patches"""
+        return torch.stack([torch.randperm(self.n_patch, generator=generator)[:self.n_mask] for _ in range(batch)]).to(torch.int32)
+
+    def forward(self, sample_values, mask_idx):
+        if not sample_values.is_cuda:
+            raise RuntimeError('MaskedEcgVit (HIP) runs on an MI355X device only (no CPU fallback)')
+        x = sample_values.contiguous().float()
+        idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
+        loss, pred = _MaskedFunction.apply(self, x, idx, *self.encoder._param_list)
+        return ModelOutput(loss=loss, logits=pred)

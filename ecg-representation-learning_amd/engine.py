@@ -71,6 +71,8 @@ class VitEngine:
             if self.N > 256:
                 raise ValueError(f'bf16 fused attention backward covers <= 256 tokens (got {self.N})')
         self.B = None
+        self._alloc_key = None
+        self.T = self.N
         self.act = None
         self.P32 = self.G32 = self.W = None
         self._ws = {}
@@ -89,12 +91,15 @@ class VitEngine:
             self.W = self.P32
         self.device = pflat.device
 
-    def _alloc(self, B):
-        if self.B == B and self.act is not None:
+    def _alloc(self, B, masked=False, m=0):
+        key = (B, masked, m)
+        if self._alloc_key == key and self.act is not None:
             return
+        self._alloc_key = key
+        self.T = self.n if masked else self.N   # tokens per record: no CLS row in the masked-pretrain trunk
         dev, T = self.device, self.dtype
-        M, Mp = B * self.N, B * self.n
-        d, f, h, N = self.d, self.f, self.h, self.N
+        M, Mp = B * self.T, B * self.n
+        d, f, h, N = self.d, self.f, self.h, self.T
         e = lambda *s, dt=T: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
         a = dict(patches=e(Mp, self.CP), tok=e(Mp, d), x0=e(M, d))
         L = []
@@ -121,6 +126,10 @@ class VitEngine:
         if T == torch.bfloat16:
             for (mm, nn) in ((d, f), (f, d), (d, d), (3 * d, d), (d, self.CP)):
                 ws = max(ws, hip.gemm_workspace_bytes(GEMM_TN, T, mm, nn, M))
+        if masked:
+            a.update(flag=torch.empty(Mp, device=dev, dtype=torch.uint8), rows=e(B * m, d), pred=e(B * m, self.CP),
+                     target=e(B * m, self.CP), dpred=e(B * m, self.CP), drows=e(B * m, d), dmasked=e(Mp, d),
+                     mloss=e(1, dt=torch.float32))
         a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
         self.act, self.B = a, B
 
@@ -144,26 +153,21 @@ class VitEngine:
         hip.gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, labels=None, weight=None, training=True, seed=0, want_mean=True):
-        """x: (B, C, L) f32 contiguous device tensor. Returns (logits (B,K) f32, loss_elem (B,K) f32 | None, loss_mean (1,) | None)."""
-        B = x.shape[0]
-        assert x.shape[1] == self.C and x.shape[2] == self.L and x.dtype == torch.float32 and x.is_contiguous()
-        self._alloc(B)
+    def _patch_embed(self, x, B):
         a, W, T = self.act, self.W, hip.code(self.dtype)
-        l, st = lib(), stream()
-        d, f, h, dh, N, n = self.d, self.f, self.h, self.dh, self.N, self.n
-        M, Mp = B * N, B * n
-        ph = self.p_hidden if training else 0.0
-        pe = self.p_emb if training else 0.0
-        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight)
         pre = 'vit.'
         # a4: patch Rearrange (integer gather) + Linear(C*P, d)
-        check(l.ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, st), 'patch_gather')
-        hip.gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], Mp, d, self.CP, self.CP, self.CP, d,
-                 epilogue=EPI_BIAS, bias=self.P32[pre + 'to_patch_embedding.1.bias'])
-        # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout
-        check(l.ecgvit_embed_finish(ptr(a['tok']), ptr(self.P32[pre + 'cls_token']), ptr(self.P32[pre + 'pos_embedding']),
-                                    ptr(a['x0']), B, n, d, pe, seed + 1, T, st), 'embed_finish')
+        check(lib().ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, stream()), 'patch_gather')
+        hip.gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], B * self.n, self.d, self.CP, self.CP,
+                 self.CP, self.d, epilogue=EPI_BIAS, bias=self.P32[pre + 'to_patch_embedding.1.bias'])
+
+    def _trunk_fwd(self, B, ph, seed):
+        """L x { x = Attn(LN(x)) + x ; x = FF(LN(x)) + x } on act['x0'] ([B*T, d]); returns the output slab"""
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        d, f, h, dh, N = self.d, self.f, self.h, self.dh, self.T
+        M = B * N
+        pre = 'vit.'
         X = a['x0']
         for i, L in enumerate(a['layers']):
             lp = f'{pre}transformer.layers.{i}.'
@@ -188,6 +192,25 @@ class VitEngine:
             hip.gemm(GEMM_NT, L['hact'], W[lp + '1.fn.net.3.weight'], L['x2'], M, d, f, f, f, d, epilogue=epi,
                      bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
             X = L['x2']
+        return X
+
+    def forward(self, x, labels=None, weight=None, training=True, seed=0, want_mean=True):
+        """x: (B, C, L) f32 contiguous device tensor. Returns (logits (B,K) f32, loss_elem (B,K) f32 | None, loss_mean (1,) | None)."""
+        B = x.shape[0]
+        assert x.shape[1] == self.C and x.shape[2] == self.L and x.dtype == torch.float32 and x.is_contiguous()
+        self._alloc(B)
+        a, T = self.act, hip.code(self.dtype)
+        l, st = lib(), stream()
+        d, N, n = self.d, self.N, self.n
+        ph = self.p_hidden if training else 0.0
+        pe = self.p_emb if training else 0.0
+        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False)
+        pre = 'vit.'
+        self._patch_embed(x, B)
+        # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout
+        check(l.ecgvit_embed_finish(ptr(a['tok']), ptr(self.P32[pre + 'cls_token']), ptr(self.P32[pre + 'pos_embedding']),
+                                    ptr(a['x0']), B, n, d, pe, seed + 1, T, st), 'embed_finish')
+        X = self._trunk_fwd(B, ph, seed)
         self.saved['xL'] = X
         # a10: x[:, 0] -> LayerNorm -> Linear(d, K)
         check(l.ecgvit_head_fwd(ptr(X), N, ptr(self.P32[pre + 'mlp_head.0.weight']), ptr(self.P32[pre + 'mlp_head.0.bias']),
@@ -200,9 +223,68 @@ class VitEngine:
                                ptr(a['loss_mean']) if want_mean else None, B * self.K, st), 'bce_fwd')
         return a['logits'], a['loss_elem'], (a['loss_mean'] if want_mean else None)
 
+    # ---------------------------------------------------------------- masked pre-train objective
+    def forward_masked(self, x, idx, training=True, seed=0):
+        """SimMIM-style step (build's own definition; absent from the reference): tokens = Linear(patches); masked tokens <-
+        mask_token; + pos[1:n+1]; trunk on n tokens (no CLS); masked rows -> Linear(d, C*P); L1 vs the raw masked patches.
+        x (B,C,L) f32; idx (B,m) int32 distinct patch indices per record. Returns (pred (B*m, C*P), loss (1,) f32)."""
+        B, m = idx.shape
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and 0 < m <= self.n
+        self._alloc(B, masked=True, m=m)
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        d, n = self.d, self.n
+        ph = self.p_hidden if training else 0.0
+        pe = self.p_emb if training else 0.0
+        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m)
+        self._patch_embed(x, B)
+        check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),
+                                         ptr(idx), ptr(a['x0']), ptr(a['flag']), B, n, m, d, T, st), 'mask_embed_finish')
+        if pe > 0:
+            self._drop_apply(a['x0'], a['x0'], B * n * d, pe, seed + 1)
+        X = self._trunk_fwd(B, ph, seed)
+        self.saved['xL'] = X
+        check(l.ecgvit_gather_rows(ptr(X), ptr(idx), ptr(a['rows']), B, n, m, d, d, d, T, st), 'gather_rows')
+        hip.gemm(GEMM_NT, a['rows'], W['pretrain.to_pixels.weight'], a['pred'], B * m, self.CP, d, d, d, self.CP, epilogue=EPI_BIAS,
+                 bias=self.P32['pretrain.to_pixels.bias'])
+        check(l.ecgvit_gather_rows(ptr(a['patches']), ptr(idx), ptr(a['target']), B, n, m, self.CP, self.CP, self.CP, T, st), 'gather_rows')
+        # L1 loss and d(loss)/d(pred) in one pass (upstream gradient 1; backward_masked re-runs it for any other upstream)
+        check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), None, B * m, self.CP,
+                                       self.CP, T, st), 'l1_loss')
+        return a['pred'], a['mloss']
+
+    def backward_masked(self, gscalar=None):
+        """loss + every gradient of the masked objective (the L1 kernel produces loss and dpred in one pass)"""
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        sv = self.saved
+        B, m, idx, pe, seed = sv['B'], sv['m'], sv['idx'], sv['pe'], sv['seed']
+        d, n = self.d, self.n
+        G = self.G32
+        if gscalar is not None:
+            check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), ptr(gscalar), B * m,
+                                           self.CP, self.CP, T, st), 'l1_loss')
+        self._colsum(a['dpred'], self.CP, G['pretrain.to_pixels.bias'], B * m, self.CP)
+        self._wgrad(a['dpred'], a['rows'], 'pretrain.to_pixels.weight', self.CP, d, B * m)
+        hip.gemm(GEMM_NN, a['dpred'], W['pretrain.to_pixels.weight'], a['drows'], B * m, d, self.CP, self.CP, d, d)
+        dX = a['dxa']
+        dX.zero_()
+        check(l.ecgvit_scatter_rows(ptr(a['drows']), ptr(idx), ptr(dX), B, n, m, d, d, d, T, st), 'scatter_rows')
+        # the classification head does not take part: its gradients are zero for this objective
+        for k in ('vit.mlp_head.0.weight', 'vit.mlp_head.0.bias', 'vit.mlp_head.1.weight', 'vit.mlp_head.1.bias', 'vit.cls_token'):
+            G[k].zero_()
+        dX = self._trunk_bwd(dX, a['dxb'])
+        if pe > 0:
+            self._drop_apply(dX, dX, B * n * d, pe, seed + 1)
+        check(l.ecgvit_mask_embed_bwd(ptr(dX), ptr(a['flag']), ptr(a['dtok']), ptr(a['dmasked']), ptr(G['vit.pos_embedding']), B, n, d,
+                                      T, st), 'mask_embed_bwd')
+        self._colsum(a['dmasked'], d, G['pretrain.mask_token'], B * n, d)
+        self._colsum(a['dtok'], d, G['vit.to_patch_embedding.1.bias'], B * n, d)
+        self._wgrad(a['dtok'], a['patches'], 'vit.to_patch_embedding.1.weight', d, self.CP, B * n)
+
     def _attn_fwd_f32(self, L, B, ph, seed):
         """f32 parity path of Attention.forward: dots = q k^T * scale (batched exact-f32 MFMA GEMM), softmax, attn v."""
-        d, h, dh, N = self.d, self.h, self.dh, self.N
+        d, h, dh, N = self.d, self.h, self.dh, self.T
         qkv, S = L['qkv'], L['probs']
         sq = (N * 3 * d, dh)
         hip.gemm(GEMM_NT, qkv, qkv, S, N, N, dh, 3 * d, 3 * d, N, alpha=self.scale, batch=(B, h), strideA=sq, strideB=sq,
@@ -250,7 +332,26 @@ class VitEngine:
                                 ptr(G[pre + 'mlp_head.1.weight']), ptr(G[pre + 'mlp_head.1.bias']),
                                 ptr(G[pre + 'mlp_head.0.weight']), ptr(G[pre + 'mlp_head.0.bias']), ptr(dX), N, B, d, self.K,
                                 T, st), 'head_bwd')
-        other = a['dxb']
+        dX = self._trunk_bwd(dX, a['dxb'])
+        for k in G:
+            if k.startswith('pretrain.'):
+                G[k].zero_()   # the masked-objective head takes no part in the supervised step
+        # ---- embedding backward
+        check(l.ecgvit_embed_bwd(ptr(dX), ptr(a['dtok']), ptr(G[pre + 'cls_token']), ptr(G[pre + 'pos_embedding']), B, n, d, pe,
+                                 seed + 1, T, st), 'embed_bwd')
+        self._colsum(a['dtok'], d, G[pre + 'to_patch_embedding.1.bias'], Mp, d)
+        self._wgrad(a['dtok'], a['patches'], pre + 'to_patch_embedding.1.weight', d, self.CP, Mp)
+
+    def _trunk_bwd(self, dX, other):
+        """backward of _trunk_fwd: consumes dX = d(loss)/d(x_L) ([B*T, d]), fills every layer's parameter gradients, returns d(x_0)"""
+        a, W, T = self.act, self.W, hip.code(self.dtype)
+        l, st = lib(), stream()
+        sv = self.saved
+        B, ph, seed = sv['B'], sv['ph'], sv['seed']
+        d, f, h, dh, N = self.d, self.f, self.h, self.dh, self.T
+        M = B * N
+        pre = 'vit.'
+        G = self.G32
         for i in reversed(range(self.Ly)):
             L = a['layers'][i]
             lp = f'{pre}transformer.layers.{i}.'
@@ -290,14 +391,10 @@ class VitEngine:
             self._ln_bwd(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
                          G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M)
             dX, other = other, dX
-        # ---- embedding backward
-        check(l.ecgvit_embed_bwd(ptr(dX), ptr(a['dtok']), ptr(G[pre + 'cls_token']), ptr(G[pre + 'pos_embedding']), B, n, d, pe,
-                                 seed + 1, T, st), 'embed_bwd')
-        self._colsum(a['dtok'], d, G[pre + 'to_patch_embedding.1.bias'], Mp, d)
-        self._wgrad(a['dtok'], a['patches'], pre + 'to_patch_embedding.1.weight', d, self.CP, Mp)
+        return dX
 
     def _attn_bwd_f32(self, L, B, ph, seed):
-        d, h, dh, N = self.d, self.h, self.dh, self.N
+        d, h, dh, N = self.d, self.h, self.dh, self.T
         a = self.act
         qkv, P, dqkv, dO, dP = L['qkv'], L['probs'], a['dqkv'], a['dattn'], a['dp']
         sq, so, sp = (N * 3 * d, dh), (N * d, dh), (h * N * N, N * N)
@@ -324,4 +421,4 @@ class VitEngine:
         if self.dtype != torch.float32:
             raise RuntimeError('attention probabilities are only materialised on the float32 path')
         B = self.saved['B']
-        return self.act['layers'][layer]['probs'].view(B, self.h, self.N, self.N)
+        return self.act['layers'][layer]['probs'].view(B, self.h, self.T, self.T)

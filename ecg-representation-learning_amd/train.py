@@ -98,7 +98,7 @@ class HipTrainStep:
         return self.lr0 * self.mult(self.step_count)
 
     def _state(self):
-        m = self.model
+        m = self.model.encoder if hasattr(self.model, 'encoder') else self.model
         m._engine()
         if self.m is None or self.m.device != m._pflat.device or self.m.numel() != m._pflat.numel():
             self.m = torch.zeros_like(m._pflat)
@@ -113,8 +113,9 @@ class HipTrainStep:
     def _allreduce(self, gflat):
         ddp.allreduce_flat_(gflat, group=self.pg)
 
-    def step(self, sample_values, labels):
-        model = self.model
+    def step_masked(self, sample_values, mask_idx):
+        """the same fused step for the masked pre-train objective; `self.model` must be a MaskedEcgVit"""
+        wrapper, model = self.model, self.model.encoder
         if not model.training:
             raise RuntimeError('train step on a model in eval mode')
         self._state()
@@ -122,14 +123,15 @@ class HipTrainStep:
         eng = model._engine()
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model._has_dropout else 0
         x = sample_values.contiguous().float()
-        y = labels.contiguous().float()
-        w = None
-        if model.loss_weight:
-            w = torch.tensor(model.loss_weight, device=y.device, dtype=torch.float32)[y.long()].contiguous()
-        logits, _, loss_mean = eng.forward(x, y, w, training=True, seed=seed, want_mean=True)
+        idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
+        pred, loss = eng.forward_masked(x, idx, training=True, seed=seed)
         model._fwd_id += 1
-        B, K = x.shape[0], eng.K
-        eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
+        eng.backward_masked()
+        self._update(model)
+        self.last_loss = loss
+        return loss, pred
+
+    def _update(self, model):
         gflat = model._gflat
         self._allreduce(gflat)
         l = hip.lib()
@@ -148,6 +150,25 @@ class HipTrainStep:
         self._flag_pending = True
         if self.sync_nonfinite:
             self._raise_if_flagged(wait=True)
+
+    def step(self, sample_values, labels):
+        model = self.model
+        if not model.training:
+            raise RuntimeError('train step on a model in eval mode')
+        self._state()
+        self._raise_if_flagged()
+        eng = model._engine()
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model._has_dropout else 0
+        x = sample_values.contiguous().float()
+        y = labels.contiguous().float()
+        w = None
+        if model.loss_weight:
+            w = torch.tensor(model.loss_weight, device=y.device, dtype=torch.float32)[y.long()].contiguous()
+        logits, _, loss_mean = eng.forward(x, y, w, training=True, seed=seed, want_mean=True)
+        model._fwd_id += 1
+        B, K = x.shape[0], eng.K
+        eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
+        self._update(model)
         self.last_loss = loss_mean
         return loss_mean, logits
 

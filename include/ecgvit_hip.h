@@ -179,6 +179,10 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
  * flag_ws: caller scratch of B*n bytes. */
 int ecgvit_mask_embed_finish(const void *tok, const float *mask_token, const float *pos, const int32_t *idx, void *X,
                              void *flag_ws, int B, int n, int m, int d, int dtype, void *stream);
+/* backward: dtok = dX on un-masked rows (0 elsewhere), dmasked = dX on masked rows (0 elsewhere; its column sum is the
+ * mask-token gradient), dpos[1+p] = sum_b dX[b*n+p], dpos[0] = 0.  flag_ws as written by ecgvit_mask_embed_finish. */
+int ecgvit_mask_embed_bwd(const void *dX, const void *flag_ws, void *dtok, void *dmasked, float *dpos, int B, int n, int d,
+                          int dtype, void *stream);
 /* gather rows: out[b*m + k] = in[b*n + idx[b,k]] */
 int ecgvit_gather_rows(const void *in, const int32_t *idx, void *out, int B, int n, int m, int64_t width, int64_t ld_in,
                        int64_t ld_out, int dtype, void *stream);

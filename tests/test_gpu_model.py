@@ -276,3 +276,52 @@ def test_patch_embedding_submodule_call():
     x = torch.from_numpy(z['x']).cuda()
     tok = m.vit.to_patch_embedding(x.unsqueeze(-2))
     assert rel_err(tok, torch.from_numpy(z['inter/embed'])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------ masked pre-train objective (a15)
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_masked_pretrain_matches_oracle(dtype):
+    """build's own SimMIM-style objective (absent from the reference => parity unpinned): HIP path vs its CPU restatement,
+    same weights, same host-generated int32 mask indices (index handling bit-exact: the gathered targets must be equal)."""
+    kw = dict(max_signal_length=1000, patch_size=20, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+              hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    conf = E.EcgVitConfig(**kw)
+    torch.manual_seed(5)
+    ref = O.OracleMaskedEcgVit(O.OracleEcgVit(config=conf)).train()
+    m = E.MaskedEcgVit(E.EcgVit(config=conf, compute_dtype=dtype))
+    m.load_state_dict(ref.state_dict(), strict=True)
+    m.cuda().train()
+    x, _ = O.synthetic_batch(6, length=1000, seed=9)
+    g = torch.Generator().manual_seed(3)
+    idx = m.random_mask_indices(6, generator=g)
+    assert idx.shape == (6, 25) and idx.dtype == torch.int32
+    o_ref = ref(x, idx)
+    o_ref.loss.backward()
+    out = m(x.cuda(), idx)
+    out.loss.backward()
+    tol = 1e-4 if dtype == F32 else 3e-2
+    assert abs(float(out.loss) - float(o_ref.loss)) / float(o_ref.loss) < tol
+    assert out.logits.shape == (6, 25, 240)
+    assert rel_err(out.logits, o_ref.logits) < (1e-4 if dtype == F32 else 3e-2)
+    eng = m.encoder._engine()
+    tgt = O.patch_gather(x, 20)[torch.arange(6).unsqueeze(-1), idx.long()].reshape(-1, 240)
+    assert torch.equal(eng.act['target'].float().cpu(), tgt.to(dtype).float())          # bit-exact gather of the masked patches
+    pm, pr = dict(m.named_parameters()), dict(ref.named_parameters())
+    for k, q in pr.items():
+        p = pm[k]
+        if q.grad is None:      # cls_token / classification head: untouched by this objective
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if k == 'encoder.vit.pos_embedding':
+            assert float(p.grad[0, 0].abs().max()) == 0.0    # CLS position slot takes no part
+        e = rel_err(p.grad, q.grad)
+        assert e < (1e-4 if dtype == F32 else 0.2), (k, e)
+    # fused masked train step runs and learns
+    ts = E.HipTrainStep(m, dict(n_step=40, learning_rate=1e-3), sync_nonfinite=True)
+    l0 = float(ts.step_masked(x.cuda(), idx)[0])
+    for _ in range(15):
+        l1 = float(ts.step_masked(x.cuda(), idx)[0])
+    assert np.isfinite(l1) and l1 < l0
+    # the supervised path still works on the shared encoder afterwards
+    y = (torch.rand(6, 71) < 0.05).float().cuda()
+    assert torch.isfinite(m.encoder(sample_values=x.cuda(), labels=y).loss)
