@@ -26,6 +26,8 @@ __device__ __forceinline__ int swz3(int row) {
     const int x = (row >> 1) & 7;
     return ((x & 1) << 2) | (x & 2) | (x >> 2);
 }
+// slot swizzle of the 64-B-row dS^T image: key bits (1,2,3) -> slot bits (0,2,1)
+__device__ __forceinline__ int dsw(int key) { return ((key >> 1) & 1) | (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1); }
 __device__ __forceinline__ int img_off(int row, int byte) { return row * 128 + ((((byte >> 4) ^ swz3(row)) << 4) | (byte & 15)); }
 
 // stage `rows_pad` rows x 128 B from global (row stride `ld` elements, rows >= nvalid zero-filled) into an image
@@ -59,6 +61,39 @@ __device__ __forceinline__ bf16x8 tr_frag32(const char *img, int row0, int col0,
     return o;
 }
 
+// ---- lane-constant address parts.  Every fragment read below starts at a row that is a multiple of 16, and the image
+// swizzle only looks at row bits 1..3, so the swizzled byte offset splits into (uniform row0 * 128) + a per-lane constant
+// computed ONCE per kernel: the inner loops then spend one v_add per base instead of ~12 VALU ops per read.
+struct RowOff { int ks[4]; };        // row_frag: lane row (lane&31), k-step ks
+struct TrOff { int lo[2], hi[2]; };  // tr_frag32: column block dt = 0/1 (32 columns each), first / second (rows + 8) read
+__device__ __forceinline__ RowOff make_row_off(int lane) {
+    RowOff r;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) r.ks[ks] = img_off(lane & 31, (ks * 16 + 8 * (lane >> 5)) * 2);
+    return r;
+}
+__device__ __forceinline__ TrOff make_tr_off(int lane) {
+    TrOff t;
+    const int g = lane >> 4, i = lane & 15;
+    const int row = 4 * (g >> 1) + (i >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int colb = (dt * 32 + (g & 1) * 16 + (i & 3) * 4) * 2;
+        t.lo[dt] = img_off(row, colb);
+        t.hi[dt] = img_off(row + 8, colb);
+    }
+    return t;
+}
+__device__ __forceinline__ bf16x8 row_frag_c(const char *img_row0, int off) { return *reinterpret_cast<const bf16x8 *>(img_row0 + off); }
+__device__ __forceinline__ bf16x8 tr_frag_c(const char *img_row0, int lo, int hi) {
+    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + lo));
+    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + hi));
+    bf16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    return o;
+}
+
 // pack accumulator registers 8*ss .. 8*ss+7 (x optional multipliers) into the bf16 B-operand fragment
 __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
     bf16x8 o;
@@ -70,7 +105,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
 // =====================================================================================================
 // forward: online softmax over 32-key tiles (running max / sum per query, O rescaled when the max moves)
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
+__global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                float *__restrict__ lse, int N, int h, float scale,
                                                                uint64_t seed, uint32_t thresh, float inv_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -80,20 +115,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t *__r
     const int d = h * 64;
     const int64_t d3 = 3 * (int64_t)d;
     const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
-    stage_image<256>(Kimg, base + d, d3, N, NK);
-    stage_image<256>(Vimg, base + 2 * d, d3, N, NK);
+    stage_image<512>(Kimg, base + d, d3, N, NK);
+    stage_image<512>(Vimg, base + 2 * d, d3, N, NK);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const float c = scale * 1.44269504088896340736f;
-    for (int qb = wave; qb < nkt; qb += 4) {
+    const RowOff ro = make_row_off(lane);
+    const TrOff to = make_tr_off(lane);
+    for (int qb = wave; qb < nkt; qb += 8) {   // 8 waves: one 32-query block each per pass (all of N <= 256 in one pass)
         const int q = qb * 32 + lr;
         const int qc = q < N ? q : N - 1;
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
-        const uint64_t rowidx = ((uint64_t)bh * N + (uint64_t)qc) * (uint64_t)N;
+        const uint32_t rowidx = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 1) & ~1);   // row pitch rounded to even: keys (2j, 2j+1) share one hash
 
         f32x16 o[2];
 #pragma unroll
@@ -107,35 +144,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t *__r
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kimg, kt * 32, ks, lane), qf[ks], s, 0, 0, 0);
-            float mx = -INFINITY;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Kimg + kt * 4096, ro.ks[ks]), qf[ks], s, 0, 0, 0);
+            if (kt == nkt - 1) {  // only the last tile can hold padded keys
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= N) s[r] = -INFINITY;
-                mx = fmaxf(mx, s[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= N) s[r] = -INFINITY;
+                }
             }
+            float mx = s[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
-            const float alpha = exp2f((m - mn) * c);       // m = -inf on the first tile -> 0
+            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0
             m = mn;
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f((s[r] - mn) * c);
+                const float p = __builtin_amdgcn_exp2f((s[r] - mn) * c);   // argument <= 0: no range fix-up needed
                 s[r] = p;
                 ls += p;
             }
             l = l * alpha + ls;                             // per-half partial sums; halves are combined after the loop
+            if (!__all(alpha == 1.0f)) {  // wave-uniform: most tiles after the first few leave every query's max untouched
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
             if (thresh) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    s[r] *= dropout_mult(seed, rowidx + key, thresh, inv_keep);
+                for (int r = 0; r < 16; r += 2) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
+                    float m0, m1;
+                    dropout_pair(seed, rowidx + key, thresh, inv_keep, m0, m1);
+                    s[r] *= m0;
+                    s[r + 1] *= m1;
                 }
             }
 #pragma unroll
@@ -143,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t *__r
                 const bf16x8 pf = pack8(s, ss);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(Vimg, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(Vimg + kt * 4096 + ss * 2048, to.lo[dt], to.hi[dt]), pf, o[dt], 0, 0, 0);
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -229,15 +274,27 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
         for (int r = 0; r < 16; ++r) { dKt[dt][r] = 0.f; dVt[dt][r] = 0.f; }
     const float c = scale * 1.44269504088896340736f;
     const int nqb = (N + 31) >> 5;
+    const RowOff ro = make_row_off(lane);
+    const TrOff to = make_tr_off(lane);
+    // dQ phase: lane-constant parts of the transposed reads (rows 4g + (i>>2) (+16), see the index permutation below)
+    const int dq_g = lane >> 4, dq_i = lane & 15;
+    const int dq_key = 4 * dq_g + (dq_i >> 2);
+    const int dq_a[2] = {dq_key * 64 + (((0 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3), dq_key * 64 + (((1 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3)};
+    int dq_b[4];
+#pragma unroll
+    for (int dhc = 0; dhc < 4; ++dhc) dq_b[dhc] = img_off(dq_key, (dhc * 16 + (dq_i & 3) * 4) * 2);
 
     for (int qb = 0; qb < nqb; ++qb) {
+        const char *Qrow = Qimg + qb * 4096, *dOrow = dOimg + qb * 4096;
+        const uint32_t NPu = (uint32_t)((N + 1) & ~1);
+        const uint32_t drop_base = ((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * NPu + (uint32_t)mykey;   // row q = qb*32
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qimg, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dOimg, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Qrow, ro.ks[ks]), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(dOrow, ro.ks[ks]), vf[ks], dp, 0, 0, 0);
         }
         // rows of s/dp = queries qb*32 + (r&3) + 8*(r>>2) + 4*lh ; column = my key
 #pragma unroll
@@ -247,11 +304,11 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * g4 + k;
-                float p = exp2f(s[r] * c - l4[k]);
+                float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
                 float g = dp[r];
                 if (thresh) {
-                    const int q = qb * 32 + 8 * g4 + 4 * lh + k;
-                    const float mlt = dropout_mult(seed, ((uint64_t)bh * N + (uint64_t)(q < N ? q : N - 1)) * (uint64_t)N + mykey, thresh, inv_keep);
+                    // element index = ((bh*N + q) * NP + key), NP = N rounded up to even (same function as the forward kernel)
+                    const float mlt = dropout_mult(seed, drop_base + (uint32_t)(8 * g4 + 4 * lh + k) * NPu, thresh, inv_keep);
                     g *= mlt;
                     s[r] = p * mlt;  // dropped probabilities feed dV
                 } else {
@@ -265,35 +322,38 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
             const bf16x8 pf = pack8(s, ss), dsf = pack8(dp, ss);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dVt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(dOimg, qb * 32 + 16 * ss, dt * 32, lane), pf, dVt[dt], 0, 0, 0);
-                dKt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag32(Qimg, qb * 32 + 16 * ss, dt * 32, lane), dsf, dKt[dt], 0, 0, 0);
+                dVt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(dOrow + ss * 2048, to.lo[dt], to.hi[dt]), pf, dVt[dt], 0, 0, 0);
+                dKt[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(Qrow + ss * 2048, to.lo[dt], to.hi[dt]), dsf, dKt[dt], 0, 0, 0);
             }
         }
-        // dS^T image [key][32 queries] (64-B rows; 32-B halves swapped on keys with bit 3 set)
+        // dS^T image [key][32 queries]: 64-B rows = 8 slots of 8 B; slot ^= dsw(key) (key bits 1,2,3 -> slot bits 0,2,1) makes
+        // the 16-lane ds_write_b64 groups and the 8-row transposed reads below both conflict-free
         char *dsb = dSimg + (qb & 1) * DSB;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             bf16x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = (bf16_t)dp[4 * g4 + k];
-            const int qbyte = (8 * g4 + 4 * lh) * 2;
-            *reinterpret_cast<bf16x4 *>(dsb + mykey * 64 + (qbyte ^ (((mykey >> 3) & 1) << 5))) = v;
+            const int slot = 2 * g4 + lh;   // queries 8*g4 + 4*lh .. +3
+            *reinterpret_cast<bf16x4 *>(dsb + mykey * 64 + ((slot ^ dsw(mykey)) << 3)) = v;
         }
-        __syncthreads();
-        // dQ[32 x 64] = dS[32 x NK] . K[NK x 64] as 8 tiles of 16x16 (qt = tile&1, dhc = tile>>1)
+        // LDS-only barrier: a full __syncthreads() would also drain the dQ global stores of the previous block
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // dQ[32 x 64] = dS[32 x NK] . K[NK x 64] as 8 tiles of 16x16 (qt = tile&1, dhc = tile>>1).  The contraction index of
+        // the 16x16x32 MFMA is permuted (k = 8g + j  <->  key = 32*st + 4g + (j&3) + 16*(j>>2)) so that each half-wave's
+        // transposed read covers 8 CONSECUTIVE key rows of the dS and K images -- conflict-free on both.
         for (int tile = wave; tile < 8; tile += NKT) {
             const int qt = tile & 1, dhc = tile >> 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const int g = lane >> 4, i = lane & 15;
-#pragma unroll
+            const int aoff = dq_a[qt], boff = dq_b[dhc];   // (tile is wave-uniform: these are selects, not scratch)
+#pragma unroll 2
             for (int st = 0; st < NKT; ++st) {
-                const int key = st * 32 + 8 * g + (i >> 2);
-                const int qb2 = (qt * 16 + (i & 3) * 4) * 2;
-                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + key * 64 + (qb2 ^ (((key >> 3) & 1) << 5))));
-                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + (key + 4) * 64 + (qb2 ^ ((((key + 4) >> 3) & 1) << 5))));
-                const int dhb = (dhc * 16 + (i & 3) * 4) * 2;
-                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + img_off(key, dhb)));
-                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + img_off(key + 4, dhb)));
+                const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + st * 2048 + aoff));
+                const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + st * 2048 + 1024 + aoff));
+                const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + st * 4096 + boff));
+                const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + st * 4096 + 2048 + boff));
                 bf16x8 a, bb;
                 a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
                 bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3]; bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3];
@@ -382,7 +442,7 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
         if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(256), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
+    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

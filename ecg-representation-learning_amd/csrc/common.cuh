@@ -90,19 +90,28 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // ---- counter-based dropout mask: keep(seed, element) is a pure function, recomputed in backward ----
 // One 32-bit murmur-style hash per PAIR of consecutive elements, 16 random bits each (threshold = p * 2^16):
 // ~4 VALU ops per element instead of the ~40 of a 64-bit mixer (the FFN epilogues touch 4e8 elements per launch).
-__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint64_t idx) {
-    uint32_t h = (uint32_t)(idx >> 1) * 0x9E3779B1u + (uint32_t)seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+// The element index is a 32-BIT WRAPPING counter (callers may pass wider integers; only the low 32 bits count): masks of
+// tensors beyond 2^32 elements repeat, which is harmless for dropout, and every index computation stays 32-bit VALU.
+__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint32_t idx) {
+    // counter + (seed * golden ratio), then the 2-multiply "lowbias32" finaliser
+    uint32_t h = (idx >> 1) + (uint32_t)seed * 0x9E3779B1u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
     return h;
 }
+// both elements of the pair starting at EVEN index idx0
+__device__ __forceinline__ void dropout_pair(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float &m0, float &m1) {
+    const uint32_t h = pair_hash(seed, idx0);
+    m0 = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+    m1 = (h >> 16) >= thresh ? inv_keep : 0.f;
+}
 // returns the multiplier: 0 or 1/(1-p)
-__device__ __forceinline__ float dropout_mult(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+__device__ __forceinline__ float dropout_mult(uint64_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
     const uint32_t h = pair_hash(seed, idx);
     const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
     return r >= thresh ? inv_keep : 0.f;
 }
 // 8 consecutive elements starting at an EVEN index: 4 hashes
-__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint64_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
+__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t h = pair_hash(seed, idx0 + 2 * k);
@@ -155,7 +164,7 @@ template <typename TO> __device__ __forceinline__ float epilogue_value(float acc
         // GELU of the value as STORED (so backward, which re-reads aux, sees the same pre-activation)
         v = gelu_erf(to_f32<TO>(from_f32<TO>(v)));
     }
-    if (e.flags & ECGVIT_EPI_DROPOUT) v *= dropout_mult(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep);
+    if (e.flags & ECGVIT_EPI_DROPOUT) v *= dropout_mult(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep);
     if (e.flags & ECGVIT_EPI_GELU_BWD) v *= gelu_erf_grad(to_f32<TO>(reinterpret_cast<const TO *>(e.aux)[m * e.ldaux + n]));
     if (e.flags & ECGVIT_EPI_RESIDUAL) v += to_f32<TO>(reinterpret_cast<const TO *>(e.residual)[m * e.ldr + n]);
     return v;

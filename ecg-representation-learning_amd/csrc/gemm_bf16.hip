@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ecgvit_gemm_desc d, E
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
             }
-            if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep, v);
+            if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
             if (e.flags & ECGVIT_EPI_GELU_BWD) {
                 const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
 #pragma unroll
@@ -355,6 +355,17 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
 
 extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     if (!d) return ECGVIT_EINVAL;
+    if (d->epilogue & ECGVIT_EPI_COLSUM) {
+        if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
+        if (d->dtype == ECGVIT_BF16 && use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
+        // generic path: plain GEMM, then the stand-alone column-sum kernel over the stored output
+        if (d->workspace_bytes < ecgvit_colsum_workspace(d->M, d->N)) return ECGVIT_EINVAL;
+        ecgvit_gemm_desc g = *d;
+        g.epilogue &= ~ECGVIT_EPI_COLSUM;
+        const int rc = ecgvit_gemm(&g, stream);
+        if (rc != ECGVIT_OK) return rc;
+        return ecgvit_colsum(d->C, d->ldc, d->colsum_out, d->workspace, d->M, d->N, d->out_dtype, stream);
+    }
     if (d->dtype == ECGVIT_F32) return ecgvit_gemm_f32_launch(d, as_stream(stream));
     if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
     return ECGVIT_EINVAL;

@@ -54,6 +54,44 @@ __device__ __forceinline__ void dma_tile(const bf16_t *__restrict__ P, int64_t l
     }
 }
 
+// ---- fast DMA path: buffer_load ... lds with a per-lane byte offset computed ONCE per output tile and the K advance in
+// the scalar offset -> zero VALU per piece (the generic path above spends ~15 VALU ops + a 64-bit address per piece).
+// Out-of-range rows fall beyond the descriptor's num_records and read as zero (hardware bounds check), so no clamping.
+// Valid when no piece can straddle a row end: K % 64 == 0 for K-contiguous operands, MN % 256 == 0 for k-major ones.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct FastOp {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[4];
+};
+template <bool KC>
+__device__ __forceinline__ FastOp fast_setup(const bf16_t *P, int64_t ld, int mn0, int MN, int kend, int wave, int lane) {
+    FastOp f;
+    // k-major operands: rows >= kend (the split's end) must read as zero -> shrink the descriptor to kend rows
+    const uint32_t bytes = KC ? (uint32_t)((int64_t)MN * ld * 2) : (uint32_t)((int64_t)kend * ld * 2);
+    f.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = wave * 4 + i;
+        if constexpr (KC) {
+            const int r = j * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            f.voff[i] = (int)(((int64_t)(mn0 + r) * ld + c * 8) * 2);
+        } else {
+            const int kr = j * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            f.voff[i] = (int)(((int64_t)kr * ld + mn0 + c * 8) * 2);
+        }
+    }
+    return f;
+}
+template <bool KC, int I0 = 0, int I1 = 4>
+__device__ __forceinline__ void fast_dma(const FastOp &f, int64_t ld, int k0, char *tile, int wave) {
+    const int soff = KC ? k0 * 2 : (int)((int64_t)k0 * ld * 2);
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(f.rsrc, (lptr_t)(tile + (wave * 4 + i) * 1024), 16, f.voff[i], soff, 0, 0);
+}
+
 // fragment: element j of lane (r = lane&31, h = lane>>5) = X[mn = base + r][k = 16*ks + 8h + j]
 template <bool KC> __device__ __forceinline__ bf16x8 frag(const char *tile, int mn_base, int ks, int lane) {
     if constexpr (KC) {
@@ -90,6 +128,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
                                                const SplitK2 &sk, int split, int m0, int n0, int wave, int lane) {
     const int M = d.M, N = d.N;
     const int wm = wave >> 2, wn = wave & 3;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of what this lane stores (EPI_COLSUM)
     float *Cs = reinterpret_cast<float *>(smem + wave * CS_WAVE_BYTES);
     const int lr = lane & 31, lh = lane >> 5;
     const int cc = (lane & 7) * 8;
@@ -136,7 +175,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
 #pragma unroll
                     for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
                 }
-                if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint64_t)m * (uint64_t)e.N + (uint64_t)n, e.drop_thresh, e.inv_keep, v);
+                if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
                 if (e.flags & ECGVIT_EPI_GELU_BWD) {
                     const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
 #pragma unroll
@@ -157,6 +196,8 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) out.set(k, v[k]);
                 st16(o, out);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cs[k] += out.get(k);
             } else {
                 float *o = reinterpret_cast<float *>(d.C) + m * d.ldc + n;
                 if (e.flags & ECGVIT_EPI_ACCUM) {
@@ -172,12 +213,26 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
             }
         }
     }
+    if (e.flags & ECGVIT_EPI_COLSUM) {
+        // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row groups, then one partial row per (tile row, wm)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cs[k] += __shfl_xor(cs[k], 8, 64);
+            cs[k] += __shfl_xor(cs[k], 16, 64);
+            cs[k] += __shfl_xor(cs[k], 32, 64);
+        }
+        if (lane < 8 && n < N) {
+            float *pr = reinterpret_cast<float *>(d.workspace) + ((int64_t)(m0 / BM) * 2 + wm) * N + n;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pr[k] = cs[k];
+        }
+    }
 }
 
 // SCHED 0: all 8 waves in lockstep (read fragments, then MFMA).
 // SCHED 1: ping-pong -- waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave issues its 8 MFMAs of a
 //          16-deep k-step while its partner reads the next fragments / issues DMA; two raw barriers per k-step.
-template <bool A_KC, bool B_KC, typename TO, int SCHED>
+template <bool A_KC, bool B_KC, typename TO, int SCHED, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -204,16 +259,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
+    FastOp fa, fb;
+    if constexpr (FAST) {
+        fa = fast_setup<A_KC>(A, d.lda, m0, M, kend, wave, lane);
+        fb = fast_setup<B_KC>(B, d.ldb, n0, N, kend, wave, lane);
+    }
     if (nk > 0) {
-        dma_tile<A_KC>(A, d.lda, m0, kbeg, M, kend, smem, wave, lane);
-        dma_tile<B_KC>(B, d.ldb, n0, kbeg, N, kend, smem + (SCHED == 3 ? 3 * TILE_BYTES : TILE_BYTES), wave, lane);
+        if constexpr (FAST) {
+            fast_dma<A_KC>(fa, d.lda, kbeg, smem, wave);
+            fast_dma<B_KC>(fb, d.ldb, kbeg, smem + TILE_BYTES, wave);
+        } else {
+            dma_tile<A_KC>(A, d.lda, m0, kbeg, M, kend, smem, wave, lane);
+            dma_tile<B_KC>(B, d.ldb, n0, kbeg, N, kend, smem + (SCHED == 3 ? 3 * TILE_BYTES : TILE_BYTES), wave, lane);
+        }
     }
     if constexpr (SCHED == 0) {
         for (int kt = 0; kt < nk; ++kt) {
             // tile kt has landed (only it is in flight); the barrier also says every wave finished reading the other stage
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (kt + 1 < nk) {
+            if (kt + 1 < nk && !(sk.ablate & 1)) {
                 char *ns = smem + ((kt + 1) & 1) * STAGE_BYTES;
                 dma_tile<A_KC>(A, d.lda, m0, kbeg + (kt + 1) * BK, M, kend, ns, wave, lane);
                 dma_tile<B_KC>(B, d.ldb, n0, kbeg + (kt + 1) * BK, N, kend, ns + TILE_BYTES, wave, lane);
@@ -292,6 +357,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
             }
             sa_i = sa_i + 1 == 3 ? 0 : sa_i + 1;
         }
+    } else if constexpr (SCHED == 4) {
+        // ping-pong with 32-deep phases: 12 fragment reads, then 16 MFMAs (512 cycles) per phase -> half the barriers of SCHED 1
+        const bool late = wave >= 4;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char *sa = smem + (kt & 1) * STAGE_BYTES;
+            const char *sb = sa + TILE_BYTES;
+            char *ns = smem + ((kt + 1) & 1) * STAGE_BYTES;
+            const bool more = (kt + 1 < nk) && !(sk.ablate & 1);
+            const int k1 = kbeg + (kt + 1) * BK;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {
+                bf16x8 a[2][4], b[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[q][j] = frag<B_KC>(sb, wn * 64 + j * 32, kp * 2 + q, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[q][i] = frag<A_KC>(sa, wm * 128 + i * 32, kp * 2 + q, lane);
+                }
+                if (more) {
+                    if (kp == 0) {
+                        dma_tile<A_KC, 0, 4>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
+                    } else {
+                        dma_tile<B_KC, 0, 4>(B, d.ldb, n0, k1, N, kend, ns + TILE_BYTES, wave, lane);
+                    }
+                }
+                if (kp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // A(kt+1) landed; B(kt+1) gets one more phase
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (kp == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // B(kt+1) landed before the tile-closing barrier
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!late) __builtin_amdgcn_s_barrier();
     } else {
         const bool late = wave >= 4;  // wave-uniform (readfirstlane above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -312,7 +427,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
                 if (more && !(sk.ablate & 1)) {  // tile kt+1 -> other stage: 3 + 3 + 2 DMA instructions over the first three k-steps
-                    if (ks == 0) {
+                    if constexpr (FAST) {
+                        if (ks == 0) {
+                            fast_dma<A_KC, 0, 3>(fa, d.lda, k1, ns, wave);
+                        } else if (ks == 1) {
+                            fast_dma<A_KC, 3, 4>(fa, d.lda, k1, ns, wave);
+                            fast_dma<B_KC, 0, 2>(fb, d.ldb, k1, ns + TILE_BYTES, wave);
+                        } else if (ks == 2) {
+                            fast_dma<B_KC, 2, 4>(fb, d.ldb, k1, ns + TILE_BYTES, wave);
+                        }
+                    } else if (ks == 0) {
                         dma_tile<A_KC, 0, 3>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
                     } else if (ks == 1) {
                         dma_tile<A_KC, 3, 4>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
@@ -489,6 +613,21 @@ __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__rest
     }
 }
 
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, int nparts, int N, float *__restrict__ out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int p = slice;
+        for (; p + 4 < nparts; p += 8) { s0 += partial[(int64_t)p * N + c]; s1 += partial[(int64_t)(p + 4) * N + c]; }
+        for (; p < nparts; p += 4) s0 += partial[(int64_t)p * N + c];
+    }
+    red[slice][lane] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && c < N) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
     if (d->layout != ECGVIT_GEMM_TN) return 1;
     const int ksteps = (d->K + BK - 1) / BK;
@@ -501,6 +640,10 @@ inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
 }  // namespace
 
 bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d) {
+    if ((d->epilogue & ECGVIT_EPI_COLSUM) &&
+        (d->layout == ECGVIT_GEMM_TN || d->out_dtype != ECGVIT_BF16 || !d->workspace || !d->colsum_out ||
+         d->workspace_bytes < (int64_t)8 * ((d->M + BM - 1) / BM) * d->N))
+        return false;   // the caller's generic fallback (GEMM, then ecgvit_colsum) handles it
     // large activations-by-weights products only; small / ragged problems stay on the 128^2 kernel
     if (d->layout == ECGVIT_GEMM_TN) return d->K >= 4096 && d->M >= 128 && d->N >= 128;
     return d->M >= 2048 && d->N >= 256;
@@ -534,12 +677,20 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     }
     EpiParams e = make_epi(d);
     dim3 grid((unsigned)(ntile * sk.splits)), block(512);
+    // fast DMA path (scalar K advance, hardware bounds check): no piece may straddle a row end, offsets must fit 31 bits
+    const bool a_kc = d->layout != ECGVIT_GEMM_TN, b_kc = d->layout == ECGVIT_GEMM_NT;
+    static const bool fast_ok = [] { const char *e = getenv("ECGVIT_GEMM_FAST"); return !(e && e[0] == '0'); }();
+    const bool fast = fast_ok && (a_kc ? d->K % 64 == 0 : d->M % 256 == 0) && (b_kc ? d->K % 64 == 0 : d->N % 256 == 0) &&
+                      (int64_t)(a_kc ? d->M : d->K) * d->lda * 2 + 65536 * d->lda < (1ll << 31) &&
+                      (int64_t)(b_kc ? d->N : d->K) * d->ldb * 2 + 65536 * d->ldb < (1ll << 31);
     static const int sched = [] { const char *e = getenv("ECGVIT_GEMM_SCHED"); return e ? atoi(e) : 1; }();
 #define LAUNCH(AK, BKC, TO)                                                                                              \
     do {                                                                                                                   \
         if (sched == 2) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 0) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 0>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 3) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 3>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (sched == 4) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 4>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (fast) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 1, true>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 1>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);  \
     } while (0)
     const bool obf = d->out_dtype == ECGVIT_BF16;
@@ -551,6 +702,10 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     }
 #undef LAUNCH
     ECGVIT_CHECK_LAUNCH();
+    if (d->epilogue & ECGVIT_EPI_COLSUM) {
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(256), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
+        ECGVIT_CHECK_LAUNCH();
+    }
     if (sk.splits > 1) {
         const int64_t MN = (int64_t)d->M * d->N;
         const int g = (int)std::min<int64_t>((MN / 4 + 255) / 256, 2048);

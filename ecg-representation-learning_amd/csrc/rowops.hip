@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__
         }
         if (thresh) {
 #pragma unroll
-            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * dropout_mult(seed, (uint64_t)(row * d + c0 + k), thresh, inv_keep));
+            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * dropout_mult(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c0 + k), thresh, inv_keep));
         }
         st16(X + row * d + c0, o);
     }
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T *__restrict__ dX
         Vec16<T> v = ld16(dX + row * d + c0);
         if (thresh) {
 #pragma unroll
-            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint64_t)(row * d + c0 + k), thresh, inv_keep));
+            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c0 + k), thresh, inv_keep));
         }
 #pragma unroll
         for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
@@ -152,23 +152,31 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T *__restrict_
     }
 }
 
-// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; per-block partial dgamma/dbeta
-template <typename T, int MAXV>
+// dx = dres + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma ; per-block partial dgamma/dbeta.
+// FUSED extras (what the NEXT backward stage needs from dx, produced while dx is still in registers):
+//   dxm = dx * dropout_mask(seed, element)   (gradient entering the preceding `dropout(Linear) + residual` site)
+//   column sums of dxm (or of dx when no dropout) = that Linear's bias gradient -> third partial row
+template <typename T, int MAXV, bool EXTRA>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict__ dy, const T *__restrict__ x,
                                                             const float *__restrict__ gamma, const float *__restrict__ mean,
                                                             const float *__restrict__ rstd, const T *__restrict__ dres,
-                                                            T *__restrict__ dx, float *__restrict__ partial, int64_t rows, int d) {
+                                                            T *__restrict__ dx, float *__restrict__ partial, int64_t rows, int d,
+                                                            T *__restrict__ dxm, uint64_t seed, uint32_t thresh, float inv_keep) {
     constexpr int VN = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][d]
+    constexpr int NP = EXTRA ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NP][d]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t wave0 = blockIdx.x * 4ll + w, nw = gridDim.x * 4ll;
     const float inv_d = 1.0f / (float)d;
-    float ag[MAXV][VN], ab[MAXV][VN], gm[MAXV][VN];
+    float ag[MAXV][VN], ab[MAXV][VN], gm[MAXV][VN], ac[EXTRA ? MAXV : 1][VN];
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * VN;
 #pragma unroll
-        for (int k = 0; k < VN; ++k) { ag[i][k] = 0.f; ab[i][k] = 0.f; gm[i][k] = c < d ? gamma[c + k] : 0.f; }
+        for (int k = 0; k < VN; ++k) {
+            ag[i][k] = 0.f; ab[i][k] = 0.f; gm[i][k] = c < d ? gamma[c + k] : 0.f;
+            if (EXTRA) ac[i][k] = 0.f;
+        }
     }
     for (int64_t r = wave0; r < rows; r += nw) {
         const float mu = mean[r], rs = rstd[r];
@@ -208,31 +216,54 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
                     ab[i][k] += dyv;
                 }
                 st16(dx + r * d + c, o);
+                if (EXTRA) {
+                    if (thresh) {
+                        Vec16<T> om;
+#pragma unroll
+                        for (int k = 0; k < VN; k += 2) {
+                            float m0, m1;
+                            dropout_pair(seed, (uint32_t)r * (uint32_t)d + (uint32_t)(c + k), thresh, inv_keep, m0, m1);
+                            om.set(k, o.get(k) * m0);
+                            om.set(k + 1, o.get(k + 1) * m1);
+                        }
+                        st16(dxm + r * d + c, om);
+#pragma unroll
+                        for (int k = 0; k < VN; ++k) ac[i][k] += om.get(k);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VN; ++k) ac[i][k] += o.get(k);   // the value as stored (rounded)
+                    }
+                }
             }
         }
     }
-    // block reduction of the 4 waves' column sums, then one partial row per block: partial[block][2][d]
+    // block reduction of the 4 waves' column sums, then one partial row per block: partial[block][NP][d]
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * VN;
         if (c < d) {
 #pragma unroll
-            for (int k = 0; k < VN; ++k) { red[(w * 2 + 0) * d + c + k] = ag[i][k]; red[(w * 2 + 1) * d + c + k] = ab[i][k]; }
+            for (int k = 0; k < VN; ++k) {
+                red[(w * NP + 0) * d + c + k] = ag[i][k];
+                red[(w * NP + 1) * d + c + k] = ab[i][k];
+                if (EXTRA) red[(w * NP + 2) * d + c + k] = ac[i][k];
+            }
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+    for (int c = threadIdx.x; c < NP * d; c += 256) {
         float s = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) s += red[ww * 2 * d + c];
-        partial[(int64_t)blockIdx.x * 2 * d + c] = s;
+        for (int ww = 0; ww < 4; ++ww) s += red[ww * NP * d + c];
+        partial[(int64_t)blockIdx.x * NP * d + c] = s;
     }
 }
 
 // out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta).
 // Block = 64 columns x 4 row-slices (each slice sums every 4th partial row, 4 loads in flight), LDS combine.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
-                                                              float *__restrict__ out0, float *__restrict__ out1, int split) {
+                                                              float *__restrict__ out0, float *__restrict__ out1, int split,
+                                                              float *__restrict__ out2 = nullptr) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
@@ -252,7 +283,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
     if (slice == 0 && c < width) {
         const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
         if (c < split) out0[c] = s;
-        else out1[c - split] = s;
+        else if (c < 2 * split || !out2) out1[c - split] = s;
+        else out2[c - 2 * split] = s;
     }
 }
 
@@ -327,7 +359,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const T *__restrict_
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         Vec16<T> v = ld16(in + i * VN);
 #pragma unroll
-        for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint64_t)(i * VN + k), thresh, inv_keep));
+        for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint32_t)i * (uint32_t)VN + (uint32_t)k, thresh, inv_keep));
         st16(out + i * VN, v);
     }
 }
@@ -404,23 +436,43 @@ int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, v
 
 static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 512); }
 
-int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln_bwd_grid(rows) * 2 * d * 4; }
+int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln_bwd_grid(rows) * 3 * d * 4; }
 
-int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
-                         void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, int dtype, void *stream) {
+static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                         void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, int dtype, void *stream,
+                         bool extra, void *dxm, float *dcolsum, float dropout_p, uint64_t seed) {
     if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048 || !partial) return ECGVIT_EINVAL;
+    if (extra && (!dcolsum || (dropout_p > 0.f && !dxm) || ((int64_t)rows * d) % 2)) return ECGVIT_EINVAL;
     const int grid = ln_bwd_grid(rows);
-    const size_t lds = (size_t)4 * 2 * d * 4;
+    const int np = extra ? 3 : 2;
+    const size_t lds = (size_t)4 * np * d * 4;
     if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     const int nv = (d + (dtype == ECGVIT_F32 ? 256 : 512) - 1) / (dtype == ECGVIT_F32 ? 256 : 512);
-#define LN_BWD(T, MV) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV>), dim3(grid), dim3(256), lds, as_stream(stream), (const T *)dy, (const T *)x, gamma, mean, rstd, (const T *)dres, (T *)dx, (float *)partial, rows, d)
+#define LN_BWD(T, MV)                                                                                                             \
+    do {                                                                                                                          \
+        if (extra) hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV, true>), dim3(grid), dim3(256), lds, as_stream(stream), (const T *)dy, (const T *)x, gamma, mean, rstd, (const T *)dres, (T *)dx, (float *)partial, rows, d, (T *)dxm, seed, th, ik); \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<T, MV, false>), dim3(grid), dim3(256), lds, as_stream(stream), (const T *)dy, (const T *)x, gamma, mean, rstd, (const T *)dres, (T *)dx, (float *)partial, rows, d, (T *)nullptr, seed, 0u, 1.f); \
+    } while (0)
     if (dtype == ECGVIT_F32) { if (nv <= 1) LN_BWD(float, 1); else if (nv <= 2) LN_BWD(float, 2); else if (nv <= 4) LN_BWD(float, 4); else LN_BWD(float, 8); }
     else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * d + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, grid, 2 * d, dgamma, dbeta, d);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, grid, np * d, dgamma, dbeta, d, extra ? dcolsum : nullptr);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
+}
+
+int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                         void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, int dtype, void *stream) {
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, partial, rows, d, dtype, stream, false, nullptr, nullptr, 0.f, 0);
+}
+
+int ecgvit_layernorm_bwd_fused(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                               void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, void *dxm, float *dcolsum,
+                               float dropout_p, uint64_t seed, int dtype, void *stream) {
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, partial, rows, d, dtype, stream, true, dxm, dcolsum, dropout_p, seed);
 }
 
 static int colsum_row_blocks(int64_t M) { return (int)std::min<int64_t>((M + 255) / 256, 256); }

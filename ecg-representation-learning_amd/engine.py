@@ -14,7 +14,7 @@ import torch
 
 from . import hip
 from .hip import lib, check, ptr, stream, GEMM_NT, GEMM_NN, GEMM_TN
-from .hip import EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_DROPOUT
+from .hip import EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM
 
 LN_EPS = 1e-5  # nn.LayerNorm default, used by vit_pytorch PreNorm / mlp_head
 
@@ -122,7 +122,7 @@ class VitEngine:
         if T == torch.float32:
             a.update(pd=e(B * h * N * N), dp=e(B * h * N * N))
         l = lib()
-        ws = max(l.ecgvit_layernorm_bwd_workspace(M, d), l.ecgvit_colsum_workspace(M, max(f, 3 * d)), 4096)
+        ws = max(l.ecgvit_layernorm_bwd_workspace(M, d), l.ecgvit_colsum_workspace(M, max(f, 3 * d)), 8 * ((M + 255) // 256) * f, 4096)
         if T == torch.bfloat16:
             for (mm, nn) in ((d, f), (f, d), (d, d), (3 * d, d), (d, self.CP)):
                 ws = max(ws, hip.gemm_workspace_bytes(GEMM_TN, T, mm, nn, M))
@@ -141,6 +141,12 @@ class VitEngine:
     def _ln_bwd(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows):
         check(lib().ecgvit_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
                                          ptr(self.act['ws']), rows, self.d, hip.code(self.dtype), stream()), 'layernorm_bwd')
+
+    def _ln_bwd_fused(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows, dxm, dcolsum, p, seed):
+        """LayerNorm backward that also emits, for the NEXT stage, the dropout-masked copy of dx and its column sums"""
+        check(lib().ecgvit_layernorm_bwd_fused(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
+                                               ptr(self.act['ws']), rows, self.d, ptr(dxm), ptr(dcolsum), p, seed,
+                                               hip.code(self.dtype), stream()), 'layernorm_bwd_fused')
 
     def _colsum(self, x, ld, out, M, N):
         check(lib().ecgvit_colsum(ptr(x), ld, ptr(out), ptr(self.act['ws']), M, N, hip.code(self.dtype), stream()), 'colsum')
@@ -352,33 +358,35 @@ class VitEngine:
         M = B * N
         pre = 'vit.'
         G = self.G32
+        # dY = gradient entering the current `dropout(Linear + bias) + residual` site (masked copy of dX when dropout is on);
+        # after the first site, the fused LayerNorm backward of the previous stage has already produced it AND its bias gradient
+        have = False
+        dY = dX
         for i in reversed(range(self.Ly)):
             L = a['layers'][i]
             lp = f'{pre}transformer.layers.{i}.'
             s0 = seed + 100 * (i + 1)
             Xin = a['x0'] if i == 0 else a['layers'][i - 1]['x2']
             # ---- FeedForward backward: x2 = drop(hact W2^T + b2) + x1
-            dY = dX
-            if ph > 0:
-                self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 4)
-                dY = a['dxm']
-            self._colsum(dY, d, G[lp + '1.fn.net.3.bias'], M, d)
+            if not have:
+                dY = dX
+                if ph > 0:
+                    self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 4)
+                    dY = a['dxm']
+                self._colsum(dY, d, G[lp + '1.fn.net.3.bias'], M, d)
             self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M)
-            epi = EPI_GELU_BWD | (EPI_DROPOUT if ph > 0 else 0)
+            # dgrad with GELU' (+ dropout mask) epilogue; the epilogue also reduces the columns = gradient of the FFN-up bias
+            epi = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0)
             hip.gemm(GEMM_NN, dY, W[lp + '1.fn.net.3.weight'], a['dh'], M, f, d, d, f, f, epilogue=epi, aux=L['hpre'], ldaux=f,
-                     dropout_p=ph, seed=s0 + 3)
-            self._colsum(a['dh'], f, G[lp + '1.fn.net.0.bias'], M, f)
+                     dropout_p=ph, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
             hip.gemm(GEMM_NN, a['dh'], W[lp + '1.fn.net.0.weight'], a['dxn'], M, d, f, f, d, d)
-            self._ln_bwd(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
-                         G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M)
+            # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
+            self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
+                               G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2)
             dX, other = other, dX  # dX = d(x1)
+            dY = a['dxm'] if ph > 0 else dX
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
-            dY = dX
-            if ph > 0:
-                self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 2)
-                dY = a['dxm']
-            self._colsum(dY, d, G[lp + '0.fn.to_out.0.bias'], M, d)
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
             hip.gemm(GEMM_NN, dY, W[lp + '0.fn.to_out.0.weight'], a['dattn'], M, d, d, d, d, d)
             if self.dtype == torch.bfloat16:
@@ -388,9 +396,18 @@ class VitEngine:
                 self._attn_bwd_f32(L, B, ph, s0 + 1)
             self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M)
             hip.gemm(GEMM_NN, a['dqkv'], W[lp + '0.fn.to_qkv.weight'], a['dxn'], M, d, 3 * d, 3 * d, d, d)
-            self._ln_bwd(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
-                         G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M)
+            if i > 0:
+                # LN1 backward; its output feeds layer i-1's FFN-down site (mask seed of layer i-1, bias net.3.bias)
+                lq = f'{pre}transformer.layers.{i - 1}.'
+                self._ln_bwd_fused(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
+                                   G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M, a['dxm'], G[lq + '1.fn.net.3.bias'], ph,
+                                   seed + 100 * i + 4)
+                have = True
+            else:
+                self._ln_bwd(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
+                             G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M)
             dX, other = other, dX
+            dY = a['dxm'] if ph > 0 else dX
         return dX
 
     def _attn_bwd_f32(self, L, B, ph, seed):

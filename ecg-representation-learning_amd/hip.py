@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')
 
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 
 _ERR = {1: 'ECGVIT_EINVAL (unsupported shape / argument)', 2: 'ECGVIT_ELAUNCH (HIP launch failure)'}
 
@@ -34,7 +34,7 @@ class GemmDesc(Structure):
         ('C', c_void_p), ('ldc', c_int64), ('strideC1', c_int64), ('strideC2', c_int64),
         ('bias', c_void_p), ('residual', c_void_p), ('ldr', c_int64), ('aux', c_void_p), ('ldaux', c_int64),
         ('alpha', c_float), ('dropout_p', c_float), ('dropout_seed', c_uint64),
-        ('workspace', c_void_p), ('workspace_bytes', c_int64),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64), ('colsum_out', c_void_p),
     ]
 
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     'ecgvit_layernorm_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
     'ecgvit_layernorm_bwd_workspace': (c_int64, [_L, _I]),
     'ecgvit_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'ecgvit_layernorm_bwd_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _I, _P]),
     'ecgvit_dropout_apply': (c_int, [_P, _P, _L, _F, _U, _I, _P]),
     'ecgvit_colsum_workspace': (c_int64, [_L, _I]),
     'ecgvit_colsum': (c_int, [_P, _L, _P, _P, _L, _I, _I, _P]),
@@ -127,7 +128,7 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
          alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-         a_off=0, b_off=0, c_off=0):
+         a_off=0, b_off=0, c_off=0, colsum_out=None):
     """A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
     d = GemmDesc()
@@ -138,6 +139,7 @@ def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, resi
     d.C, d.ldc, d.strideC1, d.strideC2 = C.data_ptr() + c_off * C.element_size(), ldc, strideC[0], strideC[1]
     d.bias, d.residual, d.ldr, d.aux, d.ldaux = ptr(bias), ptr(residual), ldr, ptr(aux), ldaux
     d.alpha, d.dropout_p, d.dropout_seed = alpha, dropout_p, seed
+    d.colsum_out = ptr(colsum_out)
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(lib().ecgvit_gemm(byref(d), stream()), 'ecgvit_gemm')

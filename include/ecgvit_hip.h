@@ -57,6 +57,9 @@ int ecgvit_abi_version(void);
 #define ECGVIT_EPI_ACCUM 16     /* v += C[m,n]   (read-modify-write of the output)                   */
 #define ECGVIT_EPI_DROPOUT 32   /* v = keep(seed, m*N+n) ? v / (1-p) : 0 ; applied after GELU / GELU_BWD,
                                    before RESIDUAL (the mask is a pure function of (seed, element))   */
+#define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
+                                   the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
+                                   max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */
 
 typedef struct ecgvit_gemm_desc {
     int32_t layout;    /* ECGVIT_GEMM_*                                             */
@@ -76,6 +79,7 @@ typedef struct ecgvit_gemm_desc {
     uint64_t dropout_seed;
     void *workspace;      /* optional split-K slabs (bf16 TN); see ecgvit_gemm_workspace */
     int64_t workspace_bytes;
+    float *colsum_out;    /* [N] f32, with ECGVIT_EPI_COLSUM */
 } ecgvit_gemm_desc;
 
 int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
@@ -107,6 +111,13 @@ int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d);
 int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
                          const void *dres, void *dx, float *dgamma, float *dbeta, void *partial,
                          int64_t rows, int d, int dtype, void *stream);
+
+/* Same, plus what the next backward stage wants from dx while it is still in registers: dxm = dx * dropout_mask(seed, i)
+ * (only written when dropout_p > 0) and dcolsum[c] = sum_rows (dropout_p > 0 ? dxm : dx) -- the gradient of the bias of the
+ * `dropout(Linear + bias) + residual` site that produced x. */
+int ecgvit_layernorm_bwd_fused(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
+                               const void *dres, void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d,
+                               void *dxm, float *dcolsum, float dropout_p, uint64_t seed, int dtype, void *stream);
 
 /* out[i] = in[i] * keep(seed, i) / (1-p): re-applies an epilogue dropout mask (element index = m*N+n, contiguous [M,N])
  * to the incoming gradient of a `dropout(acc + bias) + residual` site.  in == out allowed. */
