@@ -86,6 +86,20 @@ class GemmProbe:
                     flops_per_launch=self.flops / n)
 
 
+def pmc_traffic(kernel_key, args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+    calibration + WRITE_SIZE; tools/pmc_bench.sh).  Counters cannot be read from inside the process, so this is the value
+    measured on this same command line; null when the run differs from the profiled workload."""
+    if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512) or args.objective != 'supervised':
+        return None
+    path = os.path.join(ROOT, 'profiles', 'r01_c_pmc_traffic_base_b512.json')
+    try:
+        with open(path) as f:
+            return json.load(f)[kernel_key]['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def cpu_baseline(conf, seconds_budget=25.0, masked=False):
     """the CPU oracle (torch eager f32 restatement of the reference step) on the host cores, bounded sample (~seconds_budget)"""
     from oracle import vit_oracle as O
@@ -249,9 +263,10 @@ def main():
             r = probe.result()
             if r:
                 out['roofline'] = {
-                    'kernel': 'gemm_bf16_kernel<A_KC=1,B_KC=1,bf16 out> (Linear forward: QKV / attn-out / FFN-up / FFN-down / patch-embed)',
+                    'kernel': 'gemm_bf16_v2_kernel<A_KC=true, B_KC=true, bf16 out> (Linear forward launches: QKV / attn-out / FFN-up / '
+                              'FFN-down / patch-embed; 256x256x64 LDS-DMA tile)',
                     'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
-                    'traffic': None, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+                    'traffic': pmc_traffic('gemm_nt', args), 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
                     'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
                 }
         if not args.no_cpu_baseline and world == 1:

@@ -119,6 +119,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 struct SplitK2 {
     int splits, k_per_split;
     float *slabs;
+    int ngroup;  // n-tiles per L2-resident weight group (tile order); tiles_n = plain N-fastest order
     int ablate;  // diagnostics only (ECGVIT_GEMM_ABLATE): 1 = no DMA after the prologue, 2 = no MFMA; results are garbage
 };
 
@@ -237,9 +238,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
     const int ntile = tiles_m * tiles_n;
-    const int split = blockIdx.x / ntile;
-    const int tid = xcd_remap(blockIdx.x - split * ntile, ntile);
-    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        // split-K (weight gradients): pin every K-slice to ONE XCD (blocks b and b+8 share an XCD under round-robin dispatch;
+        // a wrong guess only costs speed).  All tiles of a slice then stream the same rows of both operands through one L2
+        // instead of eight (measured: 2.3 GB fetched per launch for 0.99 GB of operands with the tile-major order).
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else {
+        split = blockIdx.x / ntile;
+        tid = xcd_remap(blockIdx.x - split * ntile, ntile);
+    }
+    // tile order inside an XCD's contiguous run: n-tiles are taken in groups of sk.ngroup whose B (weight) panels fit the
+    // 4-MiB L2, and all m-panels are swept per group -- B is then fetched ~once per XCD instead of once per 32-tile round.
+    int tm, tn;
+    {
+        const int G = sk.ngroup, full = G * tiles_m;
+        const int ng = (tiles_n + G - 1) / G;
+        int g = tid / full;
+        g = g < ng - 1 ? g : ng - 1;
+        const int rem = tid - g * full;
+        const int w = (g == ng - 1) ? tiles_n - g * G : G;
+        tm = rem / w;
+        tn = g * G + (rem - tm * w);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = d.M, N = d.N;
     const int kbeg = split * sk.k_per_split;
@@ -525,9 +548,31 @@ template <bool A_KC, bool B_KC, typename TO>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) char smem[RING_LDS];
     const int ntile = tiles_m * tiles_n;
-    const int split = blockIdx.x / ntile;
-    const int tid = xcd_remap(blockIdx.x - split * ntile, ntile);
-    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        // split-K (weight gradients): pin every K-slice to ONE XCD (blocks b and b+8 share an XCD under round-robin dispatch;
+        // a wrong guess only costs speed).  All tiles of a slice then stream the same rows of both operands through one L2
+        // instead of eight (measured: 2.3 GB fetched per launch for 0.99 GB of operands with the tile-major order).
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else {
+        split = blockIdx.x / ntile;
+        tid = xcd_remap(blockIdx.x - split * ntile, ntile);
+    }
+    // tile order inside an XCD's contiguous run: n-tiles are taken in groups of sk.ngroup whose B (weight) panels fit the
+    // 4-MiB L2, and all m-panels are swept per group -- B is then fetched ~once per XCD instead of once per 32-tile round.
+    int tm, tn;
+    {
+        const int G = sk.ngroup, full = G * tiles_m;
+        const int ng = (tiles_n + G - 1) / G;
+        int g = tid / full;
+        g = g < ng - 1 ? g : ng - 1;
+        const int rem = tid - g * full;
+        const int w = (g == ng - 1) ? tiles_n - g * G : G;
+        tm = rem / w;
+        tn = g * G + (rem - tm * w);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int M = d.M, N = d.N;
     const int kbeg = split * sk.k_per_split;
@@ -631,9 +676,11 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
     if (d->layout != ECGVIT_GEMM_TN) return 1;
     const int ksteps = (d->K + BK - 1) / BK;
-    int s = 256 / ntile;                         // one 139-KiB block per CU: fill ONE round of the 256 CUs, never 2.1
+    // one block per CU: fill ONE round of the 256 CUs (never 2.1 rounds); a multiple of 8 slices lets each XCD own whole K-slices
+    int s = 256 / ntile;
+    if (s >= 8) s &= ~7;
     if (s < 1) s = 1;
-    s = std::min(s, std::max(1, ksteps / 16));   // keep >= 16 K-steps per split
+    s = std::min(s, std::max(1, ksteps / 16));   // keep >= 16 K-steps per slice
     return std::max(1, std::min(s, 64));
 }
 
@@ -665,6 +712,22 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     sk.k_per_split = ((d->K + BK - 1) / BK) * BK;
     static const int ablate = [] { const char *e = getenv("ECGVIT_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     sk.ablate = ablate;
+    {   // group size: the B panels of one group (G x 256 x K bf16) should sit in about half of an XCD's 4-MiB L2; the A operand
+        // is then re-read once per group, so only group when that costs less than the B re-fetches it saves
+        static const int genv = [] { const char *e = getenv("ECGVIT_GEMM_NGROUP"); return e ? atoi(e) : 0; }();
+        const double a_bytes = 2.0 * d->M * d->K, b_bytes = 2.0 * d->N * d->K;
+        const double rounds = std::max(1.0, (double)ntile / 256.0);            // 32-tile rounds per XCD
+        int best = tiles_n;
+        double best_cost = a_bytes + b_bytes * 8.0 * rounds;                   // plain order: B re-streamed every round
+        for (int G = 1; G < tiles_n; ++G) {
+            if (2.0 * G * 256.0 * d->K > 2.2e6) break;
+            const int ng = (tiles_n + G - 1) / G;
+            const double cost = a_bytes * ng + b_bytes * 8.0;
+            if (cost < best_cost) { best_cost = cost; best = G; }
+        }
+        sk.ngroup = genv > 0 ? std::min(genv, tiles_n) : best;
+        if (d->layout == ECGVIT_GEMM_TN) sk.ngroup = tiles_n;
+    }
     if (d->workspace && d->layout == ECGVIT_GEMM_TN) {
         int sp = choose_splits2(d, ntile);
         while (sp > 1 && (int64_t)sp * d->M * d->N * 4 > d->workspace_bytes) --sp;
