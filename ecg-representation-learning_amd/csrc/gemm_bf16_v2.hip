@@ -380,6 +380,84 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
             }
             sa_i = sa_i + 1 == 3 ? 0 : sa_i + 1;
         }
+    } else if constexpr (SCHED == 5) {
+        // Ping-pong with WHOLE-tile phases: a wave reads all 24 fragments of a 64-deep K-tile (R), then issues its 32 MFMAs
+        // (M, 1024 cycles) while its SIMD partner is in R; two barriers per K-tile instead of eight.  Both halves issue the
+        // DMA of a tile in the same global phase (early half: start of its R(kt) -> tile kt+1; late half: start of its
+        // M(kt) -> tile kt+2) and retire it one full tile later, so the data is visible before any wave's R of that tile.
+        const bool late = wave >= 4;
+        const bool dma_on = !(sk.ablate & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (late) {
+            if (nk > 1 && dma_on) {
+                if constexpr (FAST) {
+                    fast_dma<A_KC>(fa, d.lda, kbeg + BK, smem + STAGE_BYTES, wave);
+                    fast_dma<B_KC>(fb, d.ldb, kbeg + BK, smem + STAGE_BYTES + TILE_BYTES, wave);
+                } else {
+                    dma_tile<A_KC>(A, d.lda, m0, kbeg + BK, M, kend, smem + STAGE_BYTES, wave, lane);
+                    dma_tile<B_KC>(B, d.ldb, n0, kbeg + BK, N, kend, smem + STAGE_BYTES + TILE_BYTES, wave, lane);
+                }
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int kt = 0; kt < nk; ++kt) {
+            const char *sa = smem + (kt & 1) * STAGE_BYTES;
+            const char *sb = sa + TILE_BYTES;
+            // ---- R phase
+            if (!late && kt + 1 < nk && dma_on) {
+                char *ns = smem + ((kt + 1) & 1) * STAGE_BYTES;
+                const int k1 = kbeg + (kt + 1) * BK;
+                if constexpr (FAST) {
+                    fast_dma<A_KC>(fa, d.lda, k1, ns, wave);
+                    fast_dma<B_KC>(fb, d.ldb, k1, ns + TILE_BYTES, wave);
+                } else {
+                    dma_tile<A_KC>(A, d.lda, m0, k1, M, kend, ns, wave, lane);
+                    dma_tile<B_KC>(B, d.ldb, n0, k1, N, kend, ns + TILE_BYTES, wave, lane);
+                }
+            }
+            bf16x8 a[4][4], b[4][2];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[ks][j] = frag<B_KC>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[ks][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
+            }
+            if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // late half: tile kt+1 (issued one M phase ago) landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M phase
+            if (late && kt + 2 < nk && dma_on) {
+                char *ns = smem + (kt & 1) * STAGE_BYTES;   // stage of tile kt: every wave's R(kt) is complete
+                const int k2 = kbeg + (kt + 2) * BK;
+                if constexpr (FAST) {
+                    fast_dma<A_KC>(fa, d.lda, k2, ns, wave);
+                    fast_dma<B_KC>(fb, d.ldb, k2, ns + TILE_BYTES, wave);
+                } else {
+                    dma_tile<A_KC>(A, d.lda, m0, k2, M, kend, ns, wave, lane);
+                    dma_tile<B_KC>(B, d.ldb, n0, k2, N, kend, ns + TILE_BYTES, wave, lane);
+                }
+            }
+            if (!(sk.ablate & 2)) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // early half: tile kt+1 landed before R(kt+1)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!late) __builtin_amdgcn_s_barrier();
     } else if constexpr (SCHED == 4) {
         // ping-pong with 32-deep phases: 12 fragment reads, then 16 MFMAs (512 cycles) per phase -> half the barriers of SCHED 1
         const bool late = wave >= 4;
@@ -535,6 +613,37 @@ __device__ __forceinline__ void ring_dma(const bf16_t *__restrict__ P, int64_t l
     }
 }
 
+struct RingFast {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff[2];
+};
+template <bool KC>
+__device__ __forceinline__ RingFast ring_fast_setup(const bf16_t *P, int64_t ld, int mn0, int MN, int kend, int wave, int lane) {
+    RingFast f;
+    const uint32_t bytes = KC ? (uint32_t)((int64_t)MN * ld * 2) : (uint32_t)((int64_t)kend * ld * 2);
+    f.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = wave * 2 + i;
+        if constexpr (KC) {
+            const int r = j * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((r >> 2) & 3);
+            f.voff[i] = (int)(((int64_t)(mn0 + r) * ld + c * 8) * 2);
+        } else {
+            const int kr = j * 2 + (lane >> 5);
+            const int c = (lane & 31) ^ ((kr & 3) << 2);
+            f.voff[i] = (int)(((int64_t)kr * ld + mn0 + c * 8) * 2);
+        }
+    }
+    return f;
+}
+template <bool KC> __device__ __forceinline__ void ring_fast_dma(const RingFast &f, int64_t ld, int k0, char *tile, int wave) {
+    const int soff = KC ? k0 * 2 : (int)((int64_t)k0 * ld * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(f.rsrc, (lptr_t)(tile + (wave * 2 + i) * 1024), 16, f.voff[i], soff, 0, 0);
+}
+
 template <bool KC> __device__ __forceinline__ bf16x8 ring_frag(const char *tile, int mn_base, int ks, int lane) {
     if constexpr (KC) {
         const int row = mn_base + (lane & 31);
@@ -544,7 +653,7 @@ template <bool KC> __device__ __forceinline__ bf16x8 ring_frag(const char *tile,
     }
 }
 
-template <bool A_KC, bool B_KC, typename TO>
+template <bool A_KC, bool B_KC, typename TO, bool FAST = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) char smem[RING_LDS];
     const int ntile = tiles_m * tiles_n;
@@ -592,12 +701,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + RBK - 1) / RBK;
+    RingFast fa, fb;
+    if constexpr (FAST) {
+        fa = ring_fast_setup<A_KC>(A, d.lda, m0, M, kend, wave, lane);
+        fb = ring_fast_setup<B_KC>(B, d.ldb, n0, N, kend, wave, lane);
+    }
     // prologue: stages 0..3 in flight (empty DMA slots are issued too, so the vmcnt arithmetic below is uniform)
 #pragma unroll
     for (int t = 0; t < RSTAGES - 1; ++t) {
         const int k0 = kbeg + t * RBK;   // k0 >= kend -> every lane reads the zero word
-        ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + t * RSTAGE, wave, lane);
-        ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + t * RSTAGE + RTILE, wave, lane);
+        if constexpr (FAST) {
+            ring_fast_dma<A_KC>(fa, d.lda, min(k0, kend), smem + t * RSTAGE, wave);
+            ring_fast_dma<B_KC>(fb, d.ldb, min(k0, kend), smem + t * RSTAGE + RTILE, wave);
+        } else {
+            ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + t * RSTAGE, wave, lane);
+            ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + t * RSTAGE + RTILE, wave, lane);
+        }
     }
     int slot = 0;
     for (int t = 0; t < nk; ++t) {
@@ -607,8 +726,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc
             const int k0 = kbeg + (t + RSTAGES - 1) * RBK;
             int ps = slot + RSTAGES - 1;
             ps = ps >= RSTAGES ? ps - RSTAGES : ps;           // slot of stage t-1 == slot of stage t+4
-            ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + ps * RSTAGE, wave, lane);
-            ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + ps * RSTAGE + RTILE, wave, lane);
+            if constexpr (FAST) {
+                ring_fast_dma<A_KC>(fa, d.lda, min(k0, kend), smem + ps * RSTAGE, wave);
+                ring_fast_dma<B_KC>(fb, d.ldb, min(k0, kend), smem + ps * RSTAGE + RTILE, wave);
+            } else {
+                ring_dma<A_KC>(A, d.lda, m0, k0, M, kend, smem + ps * RSTAGE, wave, lane);
+                ring_dma<B_KC>(B, d.ldb, n0, k0, N, kend, smem + ps * RSTAGE + RTILE, wave, lane);
+            }
         }
         const char *sa = smem + slot * RSTAGE;
         const char *sb = sa + RTILE;
@@ -746,13 +870,18 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     const bool fast = fast_ok && (a_kc ? d->K % 64 == 0 : d->M % 256 == 0) && (b_kc ? d->K % 64 == 0 : d->N % 256 == 0) &&
                       (int64_t)(a_kc ? d->M : d->K) * d->lda * 2 + 65536 * d->lda < (1ll << 31) &&
                       (int64_t)(b_kc ? d->N : d->K) * d->ldb * 2 + 65536 * d->ldb < (1ll << 31);
-    static const int sched = [] { const char *e = getenv("ECGVIT_GEMM_SCHED"); return e ? atoi(e) : 1; }();
+    // schedule per layout (measured, MI355X, M = 128512): forward (NT) is fastest with 16-deep ping-pong phases, the two
+    // backward layouts (k-major B operand / both k-major) with whole-tile phases; ECGVIT_GEMM_SCHED overrides for experiments
+    static const int sched_env = [] { const char *e = getenv("ECGVIT_GEMM_SCHED"); return e ? atoi(e) : -1; }();
+    const int sched = sched_env >= 0 ? sched_env : (d->layout == ECGVIT_GEMM_NT ? 1 : 5);
 #define LAUNCH(AK, BKC, TO)                                                                                              \
     do {                                                                                                                   \
-        if (sched == 2) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        if (sched == 2 && fast && !(AK) && !(BKC)) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO, true>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (sched == 2) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 0) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 0>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 3) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 3>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 4) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 4>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
+        else if (sched == 5 && fast) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 5, true>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (fast) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 1, true>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 1>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);  \
     } while (0)
