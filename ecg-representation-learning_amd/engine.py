@@ -42,6 +42,27 @@ class ParamLayout:
         off, shape, n = self.entries[name]
         return flat[off:off + n].view(shape)
 
+    def span(self, pred):
+        """[lo, hi) element range of the flat buffer covered by the parameters whose name satisfies `pred` (must be contiguous)"""
+        sel = [(o, o + c) for n, (o, _, c) in self.entries.items() if pred(n)]
+        if not sel:
+            return None
+        lo, hi = min(a for a, _ in sel), max(b for _, b in sel)
+        inside = [n for n, (o, _, c) in self.entries.items() if lo <= o < hi]
+        assert all(pred(n) for n in inside), 'bucket is not contiguous in the flat layout'
+        return lo, _align(hi)
+
+    def buckets_in_ready_order(self, n_layers):
+        """gradient buckets in the order the backward pass completes them: head, layers L-1..0, then embedding (+ extras)"""
+        out = [('head', self.span(lambda n: n.startswith('vit.mlp_head.')))]
+        for i in reversed(range(n_layers)):
+            out.append((f'layer{i}', self.span(lambda n, i=i: n.startswith(f'vit.transformer.layers.{i}.'))))
+        out.append(('embed', self.span(lambda n: n in ('vit.pos_embedding', 'vit.cls_token') or n.startswith('vit.to_patch_embedding.'))))
+        ex = self.span(lambda n: n.startswith('pretrain.'))
+        if ex:
+            out.append(('pretrain', ex))
+        return [(k, v) for k, v in out if v]
+
 
 class VitEngine:
     """Forward / backward of EcgVit for one activation dtype (torch.float32 = parity path, torch.bfloat16 =
@@ -77,6 +98,7 @@ class VitEngine:
         self.P32 = self.G32 = self.W = None
         self._ws = {}
         self.saved = None
+        self.on_grads_ready = None   # callback(tag): a gradient bucket ('head' | 'layer{i}' | 'embed' | 'pretrain') is final
 
     # ---------------------------------------------------------------- buffers
     def bind(self, pflat, gflat, wlow=None):
@@ -287,6 +309,9 @@ class VitEngine:
         self._colsum(a['dmasked'], d, G['pretrain.mask_token'], B * n, d)
         self._colsum(a['dtok'], d, G['vit.to_patch_embedding.1.bias'], B * n, d)
         self._wgrad(a['dtok'], a['patches'], 'vit.to_patch_embedding.1.weight', d, self.CP, B * n)
+        self._ready('head')
+        self._ready('embed')
+        self._ready('pretrain')
 
     def _attn_fwd_f32(self, L, B, ph, seed):
         """f32 parity path of Attention.forward: dots = q k^T * scale (batched exact-f32 MFMA GEMM), softmax, attn v."""
@@ -338,15 +363,22 @@ class VitEngine:
                                 ptr(G[pre + 'mlp_head.1.weight']), ptr(G[pre + 'mlp_head.1.bias']),
                                 ptr(G[pre + 'mlp_head.0.weight']), ptr(G[pre + 'mlp_head.0.bias']), ptr(dX), N, B, d, self.K,
                                 T, st), 'head_bwd')
+        self._ready('head')
         dX = self._trunk_bwd(dX, a['dxb'])
         for k in G:
             if k.startswith('pretrain.'):
                 G[k].zero_()   # the masked-objective head takes no part in the supervised step
+        self._ready('pretrain')
         # ---- embedding backward
         check(l.ecgvit_embed_bwd(ptr(dX), ptr(a['dtok']), ptr(G[pre + 'cls_token']), ptr(G[pre + 'pos_embedding']), B, n, d, pe,
                                  seed + 1, T, st), 'embed_bwd')
         self._colsum(a['dtok'], d, G[pre + 'to_patch_embedding.1.bias'], Mp, d)
         self._wgrad(a['dtok'], a['patches'], pre + 'to_patch_embedding.1.weight', d, self.CP, Mp)
+        self._ready('embed')
+
+    def _ready(self, tag):
+        if self.on_grads_ready is not None:
+            self.on_grads_ready(tag)
 
     def _trunk_bwd(self, dX, other):
         """backward of _trunk_fwd: consumes dX = d(loss)/d(x_L) ([B*T, d]), fills every layer's parameter gradients, returns d(x_0)"""
@@ -408,6 +440,8 @@ class VitEngine:
                              G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M)
             dX, other = other, dX
             dY = a['dxm'] if ph > 0 else dX
+            # every gradient of layer i is final here (its net.3.bias came from the fused LN1 backward of layer i+1, earlier)
+            self._ready(f'layer{i}')
         return dX
 
     def _attn_bwd_f32(self, L, B, ph, seed):

@@ -10,7 +10,8 @@ Mirrors `ecg_transformer/models/train.py`:
 clip+AdamW pass that also refreshes the bf16 weight shadow, no per-parameter launches and no host sync in the step
 (the non-finite check of `error_if_nonfinite=True` is evaluated one step late from a device flag, or immediately with
 `sync_nonfinite=True`).  Data parallel (reference has none): one process per GPU, gradients all-reduced over
-RCCL as ONE collective over the flat gradient buffer (342 MB f32 for base: bandwidth-, not latency-bound on xGMI).
+RCCL in per-layer buckets of the flat gradient buffer (28 MB f32 each for base), each launched asynchronously the moment the
+backward pass has finished that layer (head, layers L-1..0, embedding), so the exchange overlaps the remaining backward.
 
 Logging / TensorBoard / sklearn metrics / datasets of MyTrainer are host-side and out of scope here.
 """
@@ -76,7 +77,7 @@ class HipTrainStep:
     args: dict as produced by `get_train_args` (uses optimizer, learning_rate, weight_decay, warmup_ratio, schedule, n_step).
     """
 
-    def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=False, process_group=None):
+    def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=False, process_group=None, overlap_allreduce=True):
         self.model = model
         self.args = {**get_train_args(), **(args or dict())}
         ca(optimizer=self.args['optimizer'], schedule=self.args['schedule'])
@@ -92,6 +93,8 @@ class HipTrainStep:
         self.last_loss = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.overlap = overlap_allreduce
+        self._works, self._launched, self._bucket_ranges, self._bucket_names = [], set(), {}, []
 
     # -- lr as the reference logs it: scheduler.get_last_lr() after `step_count` scheduler steps
     def get_last_lr(self):
@@ -111,7 +114,38 @@ class HipTrainStep:
 
     # -- gradient all-reduce (RCCL over xGMI): one collective over the flat gradient buffer
     def _allreduce(self, gflat):
-        ddp.allreduce_flat_(gflat, group=self.pg)
+        """N > 1: finish the gradient exchange. With overlap on, every bucket was already launched (async, on RCCL's own stream)
+        by `_bucket_ready` the moment the backward pass completed it; here we only wait for them."""
+        if self.world == 1:
+            return
+        if self.overlap:
+            for w in self._works:
+                w.wait()
+            self._works = []
+            missing = set(self._bucket_names) - self._launched
+            assert not missing, f'gradient buckets never reported ready: {missing}'
+        else:
+            ddp.allreduce_flat_(gflat, group=self.pg)
+
+    def _bucket_ready(self, tag):
+        """engine callback: the gradients of bucket `tag` are final -> start their all-reduce now, overlapped with the rest of
+        the backward pass (reverse-layer order: head, layers L-1..0, embedding)"""
+        if self.world == 1 or not self.overlap or tag not in self._bucket_ranges or tag in self._launched:
+            return
+        lo, hi = self._bucket_ranges[tag]
+        self._launched.add(tag)
+        self._works.append(dist.all_reduce(self._gflat_ref[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _arm_overlap(self, model):
+        eng = model._engine()
+        if self.world > 1 and self.overlap:
+            rng = dict(model._layout.buckets_in_ready_order(eng.Ly))
+            self._bucket_ranges, self._bucket_names = rng, list(rng)
+            self._gflat_ref = model._gflat
+            self._launched, self._works = set(), []
+            eng.on_grads_ready = self._bucket_ready
+        else:
+            eng.on_grads_ready = None
 
     def step_masked(self, sample_values, mask_idx):
         """the same fused step for the masked pre-train objective; `self.model` must be a MaskedEcgVit"""
@@ -126,6 +160,7 @@ class HipTrainStep:
         idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
         pred, loss = eng.forward_masked(x, idx, training=True, seed=seed)
         model._fwd_id += 1
+        self._arm_overlap(model)
         eng.backward_masked()
         self._update(model)
         self.last_loss = loss
@@ -167,6 +202,7 @@ class HipTrainStep:
         logits, _, loss_mean = eng.forward(x, y, w, training=True, seed=seed, want_mean=True)
         model._fwd_id += 1
         B, K = x.shape[0], eng.K
+        self._arm_overlap(model)
         eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
         self._update(model)
         self.last_loss = loss_mean

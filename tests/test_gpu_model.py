@@ -3,6 +3,8 @@
   (2) the CPU oracle on the same seeded inputs,
 f32 path within 1e-4 relative (north_star tolerance), bf16 path within bf16 rounding (stated per assert).
 Size-independent properties at the benchmark geometry: batch-slice invariance, run-to-run determinism."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -325,3 +327,53 @@ def test_masked_pretrain_matches_oracle(dtype):
     # the supervised path still works on the shared encoder afterwards
     y = (torch.rand(6, 71) < 0.05).float().cuda()
     assert torch.isfinite(m.encoder(sample_values=x.cuda(), labels=y).loss)
+
+
+# ------------------------------------------------------------------------------------------------------ data parallel on the HIP path
+def _ddp_worker(rank, world, port, out_dir, overlap):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # both ranks share cuda:0 here; gloo moves CUDA tensors via the host
+    import ecg_representation_learning_amd as E
+    from oracle import vit_oracle as O
+    torch.cuda.set_device(0)
+    conf = E.EcgVitConfig(max_signal_length=400, patch_size=20, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          intermediate_size=128, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(11)
+    m = E.EcgVit(config=conf, compute_dtype=torch.float32).cuda().train()
+    x, y = O.synthetic_batch(8, length=400, seed=77)
+    lo, hi = E.ddp.shard_range(8, rank, world)
+    ts = E.HipTrainStep(m, dict(n_step=10, warmup_ratio=0.0, learning_rate=1e-3), sync_nonfinite=True, overlap_allreduce=overlap)
+    losses = []
+    for _ in range(2):
+        loss, _ = ts.step(x[lo:hi].cuda(), y[lo:hi].cuda())
+        losses.append(float(loss))
+    torch.save(dict(p=m._pflat.cpu(), norm=ts.grad_norm(), losses=losses), os.path.join(out_dir, f'r{rank}_{int(overlap)}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_rank_data_parallel_step_equals_full_batch(tmp_path, overlap):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'r{r}_{int(overlap)}.pt')) for r in range(2))
+    assert torch.equal(r0['p'], r1['p'])                         # replicas stay identical
+    # single process, whole batch
+    conf = E.EcgVitConfig(max_signal_length=400, patch_size=20, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          intermediate_size=128, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(11)
+    m = E.EcgVit(config=conf, compute_dtype=F32).cuda().train()
+    x, y = O.synthetic_batch(8, length=400, seed=77)
+    ts = E.HipTrainStep(m, dict(n_step=10, warmup_ratio=0.0, learning_rate=1e-3), sync_nonfinite=True)
+    for _ in range(2):
+        loss, _ = ts.step(x.cuda(), y.cuda())
+    assert abs(ts.grad_norm() - r0['norm']) / r0['norm'] < 1e-4    # clip norm computed on the REDUCED gradient
+    assert max_err(m._pflat, r0['p']) < 5e-6
+    assert abs(0.5 * (r0['losses'][1] + r1['losses'][1]) - float(loss)) < 1e-5

@@ -103,3 +103,20 @@ def test_model_output_protocol():
     out = E.ModelOutput(loss=1, logits=2)
     loss, logits = out
     assert (loss, logits) == (1, 2) and out.loss == 1 and out.logits == 2
+
+
+def test_gradient_buckets_cover_flat_buffer_once_in_ready_order():
+    """DDP overlap: buckets (head, layers L-1..0, embed[, pretrain]) must tile the flat gradient buffer exactly once"""
+    conf = E.EcgVitConfig(max_signal_length=200, patch_size=20, hidden_size=32, num_hidden_layers=3, num_attention_heads=2,
+                          intermediate_size=64)
+    for wrap in (False, True):
+        m = E.EcgVit(config=conf)
+        if wrap:
+            E.MaskedEcgVit(m)
+        b = m._layout.buckets_in_ready_order(3)
+        names = [k for k, _ in b]
+        assert names == ['head', 'layer2', 'layer1', 'layer0', 'embed'] + (['pretrain'] if wrap else [])
+        cover = sorted(v for _, v in b)
+        assert cover[0][0] == 0 and cover[-1][1] == m._layout.total
+        for (a0, a1), (b0, b1) in zip(cover, cover[1:]):
+            assert a1 == b0, 'buckets must be adjacent and disjoint'
