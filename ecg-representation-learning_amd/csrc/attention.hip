@@ -17,6 +17,7 @@
 //   -> ds_read_b128 row reads (MFMA K-contiguous operand) hit 16 distinct slots per 16-lane group, and
 //   -> ds_read_b64_tr_b16 reads of 4 consecutive rows x 64 B land in the 4 different 64-B quarters of the bank row.
 #include "common.cuh"
+#include <cstdlib>
 
 namespace {
 
@@ -38,6 +39,23 @@ __device__ __forceinline__ void stage_image(char *img, const bf16_t *__restrict_
         u32x4 v = {0u, 0u, 0u, 0u};
         if (row < nvalid) v = *reinterpret_cast<const u32x4 *>(g + (int64_t)row * ld + ch * 8);
         *reinterpret_cast<u32x4 *>(img + img_off(row, ch * 16)) = v;
+    }
+}
+
+// Same image, staged by LDS-DMA (`buffer_load ... lds`): asynchronous, no VGPR round trip, all pieces of all images in flight
+// at once.  One piece = 8 image rows (1 KiB); the swizzle is applied to the per-lane SOURCE chunk; rows >= nvalid fall beyond
+// the descriptor's num_records and read as zero (hardware bounds check).  Caller waits (vmcnt(0)) and barriers.
+typedef __attribute__((address_space(3))) void *lds_void_p;
+template <int NW>
+__device__ __forceinline__ void dma_image(char *img, const bf16_t *g, int64_t ld, int nvalid, int rows_pad, int wave, int lane) {
+    const uint32_t bytes = (uint32_t)(((int64_t)(nvalid - 1) * ld + 64) * 2);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, bytes, 0x00020000);
+    const int npiece = rows_pad >> 3;
+    for (int j = wave; j < npiece; j += NW) {
+        const int row = j * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz3(row);
+        const int voff = (int)(((int64_t)row * ld + chunk * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_p)(img + j * 1024), 16, voff, 0, 0, 0);
     }
 }
 
@@ -85,13 +103,17 @@ __device__ __forceinline__ TrOff make_tr_off(int lane) {
     return t;
 }
 __device__ __forceinline__ bf16x8 row_frag_c(const char *img_row0, int off) { return *reinterpret_cast<const bf16x8 *>(img_row0 + off); }
+__device__ __forceinline__ bf16x8 join_halves(bf16x4 a, bf16x4 b) {
+    // two 8-byte halves -> one 16-byte fragment without per-element moves
+    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+    u32x4 u;
+    u[0] = ua[0]; u[1] = ua[1]; u[2] = ub[0]; u[3] = ub[1];
+    return __builtin_bit_cast(bf16x8, u);
+}
 __device__ __forceinline__ bf16x8 tr_frag_c(const char *img_row0, int lo, int hi) {
     const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + lo));
     const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + hi));
-    bf16x8 o;
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
-    o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-    return o;
+    return join_halves(a, b);
 }
 
 // pack accumulator registers 8*ss .. 8*ss+7 (x optional multipliers) into the bf16 B-operand fragment
@@ -105,6 +127,7 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
 // =====================================================================================================
 // forward: online softmax over 32-key tiles (running max / sum per query, O rescaled when the max moves)
 // =====================================================================================================
+template <bool DROP>
 __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                float *__restrict__ lse, int N, int h, float scale,
                                                                uint64_t seed, uint32_t thresh, float inv_keep) {
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
-            if (thresh) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
+            if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
@@ -212,11 +235,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 // =====================================================================================================
 // backward
 // =====================================================================================================
-template <int NKT>
+template <int NKT, bool DROP>
 __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                                  const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                                  bf16_t *__restrict__ dqkv, int N, int h, float scale,
-                                                                 uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                                 uint64_t seed, uint32_t thresh, float inv_keep, int ablate) {
     constexpr int NK = NKT * 32, NT = NKT * 64;
     constexpr int IMG = NK * 128, DSB = NK * 64;
     __shared__ __attribute__((aligned(16))) char smem[3 * IMG + 2 * DSB + 2 * NK * 4];
@@ -229,43 +252,56 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
     const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
     const bf16_t *dobase = dout + (int64_t)b * N * d + hd * 64;
     const bf16_t *obase = out + (int64_t)b * N * d + hd * 64;
-    stage_image<NT>(Qimg, base, d3, N, NK);
-    stage_image<NT>(Kimg, base + d, d3, N, NK);
-    stage_image<NT>(dOimg, dobase, d, N, NK);
-    {   // delta[q] = sum_dh dO[q][dh] * O[q][dh] ; 8 lanes per row, 16 B each
-        const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
-        for (int r0 = 0; r0 < NK; r0 += NT / 8) {
-            const int r = r0 + row;
-            float acc = 0.f;
-            if (r < N) {
-                const Vec16<bf16_t> a = ld16(dobase + (int64_t)r * d + part * 8), o = ld16(obase + (int64_t)r * d + part * 8);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int mykey = wave * 32 + lr;
+    // ---- prologue: EVERYTHING this block reads is put in flight before the first wait (one block per CU: nothing else hides
+    //      the HBM latency): three images by LDS-DMA, V fragments / dO,O rows (for delta) / LSE by ordinary loads
+    dma_image<NKT>(Qimg, base, d3, N, NK, wave, lane);
+    dma_image<NKT>(Kimg, base + d, d3, N, NK, wave, lane);
+    dma_image<NKT>(dOimg, dobase, d, N, NK, wave, lane);
+    bf16x8 kf[4], vf[4];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc += a.get(k) * o.get(k);
-            }
+    for (int ks = 0; ks < 4; ++ks) {
+        u32x4 v4 = {0u, 0u, 0u, 0u};
+        if (mykey < N) v4 = *reinterpret_cast<const u32x4 *>(base + 2 * d + (int64_t)mykey * d3 + ks * 16 + 8 * lh);
+        vf[ks] = __builtin_bit_cast(bf16x8, v4);
+    }
+    {   // delta[q] = sum_dh dO[q][dh] * O[q][dh] ; 8 lanes per row, 16 B each; all 4 passes' loads issued back to back
+        const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+        Vec16<bf16_t> va[4], vo[4];
+        float ls[4];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * (NT / 8) + row;
+            const int rc = r < N ? r : N - 1;
+            va[ps] = ld16(dobase + (int64_t)rc * d + part * 8);
+            vo[ps] = ld16(obase + (int64_t)rc * d + part * 8);
+            ls[ps] = lse[(int64_t)bh * N + rc];
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int r = ps * (NT / 8) + row;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += va[ps].get(k) * vo[ps].get(k);
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             acc += __shfl_xor(acc, 4, 64);
             if (part == 0) {
-                delta_s[r] = acc;
-                lse_s[r] = r < N ? lse[(int64_t)bh * N + r] * 1.44269504088896340736f : 0.f;
+                delta_s[r] = r < N ? acc : 0.f;
+                lse_s[r] = r < N ? ls[ps] * 1.44269504088896340736f : 0.f;
             }
         }
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int mykey = wave * 32 + lr;
-    bf16x8 kf[4], vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        u32x4 k4 = {0u, 0u, 0u, 0u}, v4 = {0u, 0u, 0u, 0u};
-        if (mykey < N) {
-            k4 = *reinterpret_cast<const u32x4 *>(base + d + (int64_t)mykey * d3 + ks * 16 + 8 * lh);
-            v4 = *reinterpret_cast<const u32x4 *>(base + 2 * d + (int64_t)mykey * d3 + ks * 16 + 8 * lh);
-        }
-        kf[ks] = __builtin_bit_cast(bf16x8, k4);
-        vf[ks] = __builtin_bit_cast(bf16x8, v4);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    {   // K fragments (B operand of S = Q K^T) straight from the staged image
+        const RowOff rk = make_row_off(lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kf[ks] = row_frag_c(Kimg + wave * 4096, rk.ks[ks]);
+    }
 
     f32x16 dKt[2], dVt[2];
 #pragma unroll
@@ -284,7 +320,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 #pragma unroll
     for (int dhc = 0; dhc < 4; ++dhc) dq_b[dhc] = img_off(dq_key, (dhc * 16 + (dq_i & 3) * 4) * 2);
 
-    for (int qb = 0; qb < nqb; ++qb) {
+    for (int qb = (ablate & 4) ? nqb : 0; qb < nqb; ++qb) {
         const char *Qrow = Qimg + qb * 4096, *dOrow = dOimg + qb * 4096;
         const uint32_t NPu = (uint32_t)((N + 1) & ~1);
         const uint32_t drop_base = ((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * NPu + (uint32_t)mykey;   // row q = qb*32
@@ -306,7 +342,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
                 const int r = 4 * g4 + k;
                 float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
                 float g = dp[r];
-                if (thresh) {
+                if constexpr (DROP) {
                     // element index = ((bh*N + q) * NP + key), NP = N rounded up to even (same function as the forward kernel)
                     const float mlt = dropout_mult(seed, drop_base + (uint32_t)(8 * g4 + 4 * lh + k) * NPu, thresh, inv_keep);
                     g *= mlt;
@@ -317,6 +353,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
                 dp[r] = p * (g - d4[k]) * scale;  // dS, in place
             }
         }
+        if (!(ablate & 2))
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             const bf16x8 pf = pack8(s, ss), dsf = pack8(dp, ss);
@@ -343,7 +380,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
         // dQ[32 x 64] = dS[32 x NK] . K[NK x 64] as 8 tiles of 16x16 (qt = tile&1, dhc = tile>>1).  The contraction index of
         // the 16x16x32 MFMA is permuted (k = 8g + j  <->  key = 32*st + 4g + (j&3) + 16*(j>>2)) so that each half-wave's
         // transposed read covers 8 CONSECUTIVE key rows of the dS and K images -- conflict-free on both.
-        for (int tile = wave; tile < 8; tile += NKT) {
+        for (int tile = (ablate & 1) ? 8 : wave; tile < 8; tile += NKT) {
             const int qt = tile & 1, dhc = tile >> 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const int g = lane >> 4, i = lane & 15;
@@ -354,31 +391,40 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
                 const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(dsb + st * 2048 + 1024 + aoff));
                 const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + st * 4096 + boff));
                 const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(Kimg + st * 4096 + 2048 + boff));
-                bf16x8 a, bb;
-                a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
-                bb[0] = b0[0]; bb[1] = b0[1]; bb[2] = b0[2]; bb[3] = b0[3]; bb[4] = b1[0]; bb[5] = b1[1]; bb[6] = b1[2]; bb[7] = b1[3];
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bb, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(b0, b1), join_halves(a0, a1), acc, 0, 0, 0);   // dQ^T tile: D[dh][q]
             }
-            const int dh = dhc * 16 + i;
+            // lane (i = query, g -> 4 consecutive dh): one 8-byte store; the four g-groups of a query form 32 contiguous bytes
+            const int q = qb * 32 + qt * 16 + i;
+            if (q < N) {
+                bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = qb * 32 + qt * 16 + g * 4 + r;
-                if (q < N) dqkv[((int64_t)b * N + q) * d3 + hd * 64 + dh] = (bf16_t)acc[r];
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
+                *reinterpret_cast<bf16x4 *>(dqkv + ((int64_t)b * N + q) * d3 + hd * 64 + dhc * 16 + 4 * g) = v;
             }
         }
     }
-    if (mykey < N) {
-        bf16_t *dk = dqkv + ((int64_t)b * N + mykey) * d3 + d + hd * 64, *dv = dk + d;
+    // ---- epilogue: dK^T / dV^T (dh on rows, key on the lane) -> [key][dh] rows in the now idle Q / dO images -> 128-B row stores
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                bf16x4 a, v;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            bf16x4 a, v;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { a[k] = (bf16_t)dKt[dt][4 * g4 + k]; v[k] = (bf16_t)dVt[dt][4 * g4 + k]; }
-                *reinterpret_cast<bf16x4 *>(dk + dt * 32 + 8 * g4 + 4 * lh) = a;
-                *reinterpret_cast<bf16x4 *>(dv + dt * 32 + 8 * g4 + 4 * lh) = v;
-            }
+            for (int k = 0; k < 4; ++k) { a[k] = (bf16_t)dKt[dt][4 * g4 + k]; v[k] = (bf16_t)dVt[dt][4 * g4 + k]; }
+            const int off = img_off(mykey, (dt * 32 + 8 * g4 + 4 * lh) * 2);
+            *reinterpret_cast<bf16x4 *>(Qimg + off) = a;
+            *reinterpret_cast<bf16x4 *>(dOimg + off) = v;
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < NK * 8; c += NT) {
+        const int row = c >> 3, ch = c & 7;
+        if (row < N) {
+            bf16_t *dst = dqkv + ((int64_t)b * N + row) * d3 + d + hd * 64 + ch * 8;
+            *reinterpret_cast<u32x4 *>(dst) = *reinterpret_cast<const u32x4 *>(Qimg + img_off(row, ch * 16));
+            *reinterpret_cast<u32x4 *>(dst + d) = *reinterpret_cast<const u32x4 *>(dOimg + img_off(row, ch * 16));
+        }
     }
 }
 
@@ -439,10 +485,12 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
     const size_t lds = (size_t)((N + 31) / 32) * 32 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
+        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
+        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_bf16_kernel, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
+    if (th) hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
+    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<false>, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
@@ -454,10 +502,11 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     dim3 grid((unsigned)(B * h));
-    if (N <= 128)
-        hipLaunchKernelGGL(attn_bwd_bf16_kernel<4>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik);
-    else
-        hipLaunchKernelGGL(attn_bwd_bf16_kernel<8>, grid, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik);
+    static const int ablate = [] { const char *e = getenv("ECGVIT_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // diagnostics only
+#define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, ablate)
+    if (N <= 128) { if (th) BWD(4, true); else BWD(4, false); }
+    else { if (th) BWD(8, true); else BWD(8, false); }
+#undef BWD
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

@@ -79,10 +79,10 @@ template <bool KC> __device__ __forceinline__ bf16x8 frag_load(const char *S, in
         const char *p = S + k * MN_ROW_BYTES + col * 2;
         const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p));
         const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p + 4 * MN_ROW_BYTES));
-        bf16x8 o;
-        o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-        o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-        return o;
+        const u32x2 ul = __builtin_bit_cast(u32x2, lo), uh = __builtin_bit_cast(u32x2, hi);
+        u32x4 u;
+        u[0] = ul[0]; u[1] = ul[1]; u[2] = uh[0]; u[3] = uh[1];
+        return __builtin_bit_cast(bf16x8, u);
     }
 }
 
