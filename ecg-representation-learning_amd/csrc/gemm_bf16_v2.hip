@@ -123,13 +123,99 @@ struct SplitK2 {
     int ablate;  // diagnostics only (ECGVIT_GEMM_ABLATE): 1 = no DMA after the prologue, 2 = no MFMA; results are garbage
 };
 
+// Finish one 8-column piece of an output row: split-K slab store, or alpha / bias / GELU (+aux) / dropout / GELU' / residual /
+// accumulate, then a 16-B (bf16) or 2 x 16-B (f32) store.  `cs` accumulates the column sums of what is stored (EPI_COLSUM).
+template <typename TO>
+__device__ __forceinline__ void epi_row8(const f32x4 c0, const f32x4 c1, int64_t m, int n, const ecgvit_gemm_desc &d,
+                                         const EpiParams &e, const SplitK2 &sk, int split, float (&cs)[8]) {
+    const int M = d.M, N = d.N;
+    if (m >= M || n >= N) return;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = c0[k]; v[4 + k] = c1[k]; }
+    if (sk.splits > 1) {
+        float *o = sk.slabs + ((int64_t)split * M + m) * N + n;
+        *reinterpret_cast<f32x4 *>(o) = c0;
+        *reinterpret_cast<f32x4 *>(o + 4) = c1;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
+    if (e.flags & ECGVIT_EPI_BIAS) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(e.bias + n), b1 = *reinterpret_cast<const f32x4 *>(e.bias + n + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+    }
+    if constexpr (sizeof(TO) == 2) {
+        if (e.flags & ECGVIT_EPI_GELU) {
+            Vec16<bf16_t> pre;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
+            st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
+        }
+        if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
+        if (e.flags & ECGVIT_EPI_GELU_BWD) {
+            const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
+        }
+        if (e.flags & ECGVIT_EPI_RESIDUAL) {
+            const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += res.get(k);
+        }
+        bf16_t *o = reinterpret_cast<bf16_t *>(d.C) + m * d.ldc + n;
+        if (e.flags & ECGVIT_EPI_ACCUM) {
+            const Vec16<bf16_t> old = ld16(o);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += old.get(k);
+        }
+        Vec16<bf16_t> out;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out.set(k, v[k]);
+        st16(o, out);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cs[k] += out.get(k);
+    } else {
+        float *o = reinterpret_cast<float *>(d.C) + m * d.ldc + n;
+        if (e.flags & ECGVIT_EPI_ACCUM) {
+            const f32x4 o0 = *reinterpret_cast<const f32x4 *>(o), o1 = *reinterpret_cast<const f32x4 *>(o + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += o0[k]; v[4 + k] += o1[k]; }
+        }
+        f32x4 w0, w1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w0[k] = v[k]; w1[k] = v[4 + k]; }
+        *reinterpret_cast<f32x4 *>(o) = w0;
+        *reinterpret_cast<f32x4 *>(o + 4) = w1;
+    }
+}
+
+__device__ __forceinline__ void epi_colsum_flush(float (&cs)[8], const ecgvit_gemm_desc &d, const EpiParams &e, int m0, int n, int wm,
+                                                 int lane) {
+    if (!(e.flags & ECGVIT_EPI_COLSUM)) return;
+    // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row groups, then one partial row per (tile row, wm)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cs[k] += __shfl_xor(cs[k], 8, 64);
+        cs[k] += __shfl_xor(cs[k], 16, 64);
+        cs[k] += __shfl_xor(cs[k], 32, 64);
+    }
+    if (lane < 8 && n < d.N) {
+        float *pr = reinterpret_cast<float *>(d.workspace) + ((int64_t)(m0 / BM) * 2 + wm) * d.N + n;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pr[k] = cs[k];
+    }
+}
+
 // Drain one wave's 128 x 64 accumulator block through its private LDS patch (two 64-row passes) and store 128-B row segments.
 template <typename TO>
 __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, const ecgvit_gemm_desc &d, const EpiParams &e,
                                                const SplitK2 &sk, int split, int m0, int n0, int wave, int lane) {
-    const int M = d.M, N = d.N;
     const int wm = wave >> 2, wn = wave & 3;
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums of what this lane stores (EPI_COLSUM)
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float *Cs = reinterpret_cast<float *>(smem + wave * CS_WAVE_BYTES);
     const int lr = lane & 31, lh = lane >> 5;
     const int cc = (lane & 7) * 8;
@@ -147,87 +233,43 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const int rr = p * 8 + (lane >> 3);
-            const int64_t m = m0 + wm * 128 + hh * 64 + rr;
             const f32x4 c0 = *reinterpret_cast<const f32x4 *>(&Cs[rr * CS_LD + cc]);
             const f32x4 c1 = *reinterpret_cast<const f32x4 *>(&Cs[rr * CS_LD + cc + 4]);
-            if (m >= M || n >= N) continue;
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] = c0[k]; v[4 + k] = c1[k]; }
-            if (sk.splits > 1) {
-                float *o = sk.slabs + ((int64_t)split * M + m) * N + n;
-                *reinterpret_cast<f32x4 *>(o) = c0;
-                *reinterpret_cast<f32x4 *>(o + 4) = c1;
-                continue;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
-            if (e.flags & ECGVIT_EPI_BIAS) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4 *>(e.bias + n), b1 = *reinterpret_cast<const f32x4 *>(e.bias + n + 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
-            }
-            if constexpr (sizeof(TO) == 2) {
-                if (e.flags & ECGVIT_EPI_GELU) {
-                    Vec16<bf16_t> pre;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
-                    st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
-                }
-                if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
-                if (e.flags & ECGVIT_EPI_GELU_BWD) {
-                    const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
-                }
-                if (e.flags & ECGVIT_EPI_RESIDUAL) {
-                    const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += res.get(k);
-                }
-                bf16_t *o = reinterpret_cast<bf16_t *>(d.C) + m * d.ldc + n;
-                if (e.flags & ECGVIT_EPI_ACCUM) {
-                    const Vec16<bf16_t> old = ld16(o);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] += old.get(k);
-                }
-                Vec16<bf16_t> out;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) out.set(k, v[k]);
-                st16(o, out);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) cs[k] += out.get(k);
-            } else {
-                float *o = reinterpret_cast<float *>(d.C) + m * d.ldc + n;
-                if (e.flags & ECGVIT_EPI_ACCUM) {
-                    const f32x4 o0 = *reinterpret_cast<const f32x4 *>(o), o1 = *reinterpret_cast<const f32x4 *>(o + 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { v[k] += o0[k]; v[4 + k] += o1[k]; }
-                }
-                f32x4 w0, w1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { w0[k] = v[k]; w1[k] = v[4 + k]; }
-                *reinterpret_cast<f32x4 *>(o) = w0;
-                *reinterpret_cast<f32x4 *>(o + 4) = w1;
-            }
+            epi_row8<TO>(c0, c1, (int64_t)m0 + wm * 128 + hh * 64 + rr, n, d, e, sk, split, cs);
         }
     }
-    if (e.flags & ECGVIT_EPI_COLSUM) {
-        // lanes with equal (lane & 7) hold the same 8 columns: fold the 8 row groups, then one partial row per (tile row, wm)
+    epi_colsum_flush(cs, d, e, m0, n, wm, lane);
+}
+
+// Same, through an 8-KiB patch per wave (32 rows x 64 f32, 16-B chunk index ^= row&1) carved out of ONE 64-KiB stage, so the
+// other stage can already receive the next tile's first K-tile (persistent kernel).  Four 32-row passes.
+template <typename TO>
+__device__ __forceinline__ void epilogue_store_small(f32x16 (&acc)[4][2], char *stage, const ecgvit_gemm_desc &d, const EpiParams &e,
+                                                     const SplitK2 &sk, int split, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    char *Cs = stage + wave * 8192;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int cq = lane & 7;           // 8-column piece: 16-B chunks 2cq, 2cq+1
+    const int n = n0 + wn * 64 + cq * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            cs[k] += __shfl_xor(cs[k], 8, 64);
-            cs[k] += __shfl_xor(cs[k], 16, 64);
-            cs[k] += __shfl_xor(cs[k], 32, 64);
-        }
-        if (lane < 8 && n < N) {
-            float *pr = reinterpret_cast<float *>(d.workspace) + ((int64_t)(m0 / BM) * 2 + wm) * N + n;
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pr[k] = cs[k];
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                *reinterpret_cast<float *>(Cs + row * 256 + ((((j * 8 + (lr >> 2)) ^ (row & 1)) << 4) | ((lr & 3) << 2))) = acc[i][j][r];
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rr = p * 8 + (lane >> 3);
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * 256 + (((2 * cq) ^ (rr & 1)) << 4));
+            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(Cs + rr * 256 + (((2 * cq + 1) ^ (rr & 1)) << 4));
+            epi_row8<TO>(c0, c1, (int64_t)m0 + wm * 128 + i * 32 + rr, n, d, e, sk, split, cs);
         }
     }
+    epi_colsum_flush(cs, d, e, m0, n, wm, lane);
 }
 
 // SCHED 0: all 8 waves in lockstep (read fragments, then MFMA).
@@ -762,6 +804,195 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_ring_kernel(ecgvit_gemm_desc
     epilogue_store<TO>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent variant (fast-DMA shapes only): one 512-thread block per CU walks a list of output tiles (or (tile, K-slice)
+// items).  After a tile's main loop the FIRST K-tile of the next item is put in flight into the idle stage BEFORE the
+// epilogue runs out of the other stage, so the ~1-1.5 us HBM/L2 prologue latency of every tile (7-9 % of a K = 768 tile)
+// is hidden behind the epilogue's LDS transpose and global stores.  Main loops: SCHED 1 (16-deep ping-pong, forward) and
+// SCHED 5 (whole-tile ping-pong, backward layouts); stage parity p0 alternates so a tile always starts in the prefetched stage.
+struct Item {
+    int split, m0, n0, kbeg, kend, nk;
+};
+__device__ __forceinline__ Item decode_item(int it, const ecgvit_gemm_desc &d, const SplitK2 &sk, int tiles_m, int tiles_n) {
+    const int ntile = tiles_m * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        const int r = sk.splits >> 3, x = it & 7, q = it >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else {
+        split = it / ntile;
+        tid = xcd_remap(it - split * ntile, ntile);
+    }
+    const int G = sk.ngroup, full = G * tiles_m;
+    const int ng = (tiles_n + G - 1) / G;
+    int g = tid / full;
+    g = g < ng - 1 ? g : ng - 1;
+    const int rem = tid - g * full;
+    const int w = (g == ng - 1) ? tiles_n - g * G : G;
+    const int tm = rem / w, tn = g * G + (rem - tm * w);
+    Item o;
+    o.split = split;
+    o.m0 = tm * BM;
+    o.n0 = tn * BN;
+    o.kbeg = split * sk.k_per_split;
+    o.kend = min(d.K, o.kbeg + sk.k_per_split);
+    o.nk = (o.kend - o.kbeg + BK - 1) / BK;
+    o.nk = o.nk > 0 ? o.nk : 0;
+    return o;
+}
+
+template <bool A_KC, bool B_KC, typename TO, int SCHED>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pers_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n,
+                                                                int nitems) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    const int M = d.M, N = d.N;
+    const bf16_t *A = reinterpret_cast<const bf16_t *>(d.A);
+    const bf16_t *B = reinterpret_cast<const bf16_t *>(d.B);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wave >= 4;
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    Item cur = decode_item(it, d, sk, tiles_m, tiles_n);
+    FastOp fa = fast_setup<A_KC>(A, d.lda, cur.m0, M, cur.kend, wave, lane);
+    FastOp fb = fast_setup<B_KC>(B, d.ldb, cur.n0, N, cur.kend, wave, lane);
+    int p0 = 0;   // stage of the current item's K-tile 0
+    if (cur.nk > 0) {
+        fast_dma<A_KC>(fa, d.lda, cur.kbeg, smem, wave);
+        fast_dma<B_KC>(fb, d.ldb, cur.kbeg, smem + TILE_BYTES, wave);
+    }
+    for (;;) {
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int nk = cur.nk, kbeg = cur.kbeg;
+        // ================= main loop =================
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // K-tile 0 visible to everyone (and the previous epilogue's patch is drained)
+        if constexpr (SCHED == 1) {
+            if (late) __builtin_amdgcn_s_barrier();
+            for (int kt = 0; kt < nk; ++kt) {
+                const char *sa = smem + ((kt + p0) & 1) * STAGE_BYTES;
+                const char *sb = sa + TILE_BYTES;
+                char *ns = smem + ((kt + 1 + p0) & 1) * STAGE_BYTES;
+                const bool more = kt + 1 < nk;
+                const int k1 = kbeg + (kt + 1) * BK;
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks) {
+                    bf16x8 a[4], b[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[j] = frag<B_KC>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[i] = frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
+                    if (more) {
+                        if (ks == 0) {
+                            fast_dma<A_KC, 0, 3>(fa, d.lda, k1, ns, wave);
+                        } else if (ks == 1) {
+                            fast_dma<A_KC, 3, 4>(fa, d.lda, k1, ns, wave);
+                            fast_dma<B_KC, 0, 2>(fb, d.ldb, k1, ns + TILE_BYTES, wave);
+                        } else if (ks == 2) {
+                            fast_dma<B_KC, 2, 4>(fb, d.ldb, k1, ns + TILE_BYTES, wave);
+                        }
+                    }
+                    if (ks == BK / 16 - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!late) __builtin_amdgcn_s_barrier();
+        } else {
+            if (late) {
+                if (nk > 1) {
+                    fast_dma<A_KC>(fa, d.lda, kbeg + BK, smem + ((1 + p0) & 1) * STAGE_BYTES, wave);
+                    fast_dma<B_KC>(fb, d.ldb, kbeg + BK, smem + ((1 + p0) & 1) * STAGE_BYTES + TILE_BYTES, wave);
+                }
+                __builtin_amdgcn_s_barrier();
+            }
+            for (int kt = 0; kt < nk; ++kt) {
+                const char *sa = smem + ((kt + p0) & 1) * STAGE_BYTES;
+                const char *sb = sa + TILE_BYTES;
+                if (!late && kt + 1 < nk) {
+                    char *ns = smem + ((kt + 1 + p0) & 1) * STAGE_BYTES;
+                    fast_dma<A_KC>(fa, d.lda, kbeg + (kt + 1) * BK, ns, wave);
+                    fast_dma<B_KC>(fb, d.ldb, kbeg + (kt + 1) * BK, ns + TILE_BYTES, wave);
+                }
+                bf16x8 a[4][4], b[4][2];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) b[ks][j] = frag<B_KC>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a[ks][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks, lane);
+                }
+                if (late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (late && kt + 2 < nk) {
+                    char *ns = smem + ((kt + p0) & 1) * STAGE_BYTES;
+                    fast_dma<A_KC>(fa, d.lda, kbeg + (kt + 2) * BK, ns, wave);
+                    fast_dma<B_KC>(fb, d.ldb, kbeg + (kt + 2) * BK, ns + TILE_BYTES, wave);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (!late) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!late) __builtin_amdgcn_s_barrier();
+        }
+        // ================= hand-over: prefetch the next item, then drain this one =================
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // nobody reads either stage any more
+        const int last_stage = nk > 0 ? ((nk - 1 + p0) & 1) : (p0 ^ 1);
+        const int next_it = it + (int)gridDim.x;
+        const bool has_next = next_it < nitems;
+        const Item done = cur;
+        if (has_next) {
+            cur = decode_item(next_it, d, sk, tiles_m, tiles_n);
+            fa = fast_setup<A_KC>(A, d.lda, cur.m0, M, cur.kend, wave, lane);
+            fb = fast_setup<B_KC>(B, d.ldb, cur.n0, N, cur.kend, wave, lane);
+            if (cur.nk > 0) {
+                char *ns = smem + (last_stage ^ 1) * STAGE_BYTES;
+                fast_dma<A_KC>(fa, d.lda, cur.kbeg, ns, wave);
+                fast_dma<B_KC>(fb, d.ldb, cur.kbeg, ns + TILE_BYTES, wave);
+            }
+        }
+        epilogue_store_small<TO>(acc, smem + last_stage * STAGE_BYTES, d, e, sk, done.split, done.m0, done.n0, wave, lane);
+        if (!has_next) break;
+        it = next_it;
+        p0 = last_stage ^ 1;
+    }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
                                                              TO *__restrict__ C, int64_t ldc, EpiParams e) {
@@ -872,10 +1103,17 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
                       (int64_t)(b_kc ? d->N : d->K) * d->ldb * 2 + 65536 * d->ldb < (1ll << 31);
     // schedule per layout (measured, MI355X, M = 128512): forward (NT) is fastest with 16-deep ping-pong phases, the two
     // backward layouts (k-major B operand / both k-major) with whole-tile phases; ECGVIT_GEMM_SCHED overrides for experiments
+    static const bool pers_ok = [] { const char *e = getenv("ECGVIT_GEMM_PERSIST"); return !(e && e[0] == '0'); }();
     static const int sched_env = [] { const char *e = getenv("ECGVIT_GEMM_SCHED"); return e ? atoi(e) : -1; }();
     const int sched = sched_env >= 0 ? sched_env : (d->layout == ECGVIT_GEMM_NT ? 1 : 5);
+    const int nitems = ntile * sk.splits;
+    // measured: persistence pays for the forward layout (+2..6 %); the whole-tile backward schedule is register-bound (no gain)
+    const bool persist = pers_ok && fast && sched == 1 && d->layout == ECGVIT_GEMM_NT && !sk.ablate;
+    dim3 pgrid((unsigned)std::min(nitems, 256));
 #define LAUNCH(AK, BKC, TO)                                                                                              \
     do {                                                                                                                   \
+        if (persist && sched == 1) { hipLaunchKernelGGL((gemm_bf16_pers_kernel<AK, BKC, TO, 1>), pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems); break; } \
+        if (persist && sched == 5) { hipLaunchKernelGGL((gemm_bf16_pers_kernel<AK, BKC, TO, 5>), pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems); break; } \
         if (sched == 2 && fast && !(AK) && !(BKC)) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO, true>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 2) hipLaunchKernelGGL((gemm_bf16_ring_kernel<AK, BKC, TO>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \
         else if (sched == 0) hipLaunchKernelGGL((gemm_bf16_v2_kernel<AK, BKC, TO, 0>), grid, block, 0, s, *d, e, sk, tiles_m, tiles_n); \

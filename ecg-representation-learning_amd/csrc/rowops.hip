@@ -434,7 +434,7 @@ int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, v
     return ECGVIT_OK;
 }
 
-static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 512); }
+static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 768); }  // 150 VGPRs -> 3 resident blocks per CU
 
 int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln_bwd_grid(rows) * 3 * d * 4; }
 
