@@ -230,7 +230,7 @@ __device__ __forceinline__ void epilogue_store(f32x16 (&acc)[4][2], char *smem, 
                 for (int r = 0; r < 16; ++r)
                     Cs[(ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS_LD + j * 32 + lr] = acc[hh * 2 + ii][j][r];
         // same-wave LDS ops execute in order: the reads below see the writes above
-#pragma unroll 2
+#pragma unroll 1
         for (int p = 0; p < 8; ++p) {
             const int rr = p * 8 + (lane >> 3);
             const f32x4 c0 = *reinterpret_cast<const f32x4 *>(&Cs[rr * CS_LD + cc]);
@@ -261,7 +261,7 @@ __device__ __forceinline__ void epilogue_store_small(f32x16 (&acc)[4][2], char *
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
                 *reinterpret_cast<float *>(Cs + row * 256 + ((((j * 8 + (lr >> 2)) ^ (row & 1)) << 4) | ((lr & 3) << 2))) = acc[i][j][r];
             }
-#pragma unroll
+#pragma unroll 1   // keep the flag-dispatched epilogue body ONCE per pass: the fully unrolled form is >100 KiB of code (I-cache)
         for (int p = 0; p < 4; ++p) {
             const int rr = p * 8 + (lane >> 3);
             const f32x4 c0 = *reinterpret_cast<const f32x4 *>(Cs + rr * 256 + (((2 * cq) ^ (rr & 1)) << 4));
