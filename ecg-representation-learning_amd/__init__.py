@@ -8,8 +8,9 @@ fails loudly when the HIP library is absent (no CPU / eager fallback by design).
 from .check_args import ca, CheckArg
 from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT, MaskedEcgVit
 from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
+from .transform import FusedInputTransform
 from . import hip
 from . import ddp
 
 __all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'get_train_args', 'lr_multiplier',
-           'HipTrainStep', 'clip_grad_norm_', 'hip', 'ddp']
+           'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'hip', 'ddp']

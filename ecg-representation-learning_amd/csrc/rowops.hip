@@ -10,16 +10,34 @@ namespace {
 // patch gather: out[(b*n+p)*ld + j*C + c] = x[b][c][p*P + j]      (integer indexing, bit-exact)
 // One block = PB consecutive patches of one record: C coalesced row segments -> LDS -> PB contiguous rows.
 // =====================================================================================================
-template <typename T>
+// XF = fused input transforms of the reference data pipeline (preprocess/transform.py, wired at ptb_dataset.py:132-149), applied
+// while the raw record streams through LDS -- no separate pass over the (B, 12, L) tensor:
+//   Normalize    (x - mean[c]) * inv_std[c]                       (transform.py:18-35)
+//   TimeEndPad   samples >= L_raw read as 0 (the record is zero-padded to L = n * P)   (:140-154)
+//   TimeOut      samples in [t0[b], t0[b] + tlen[b]) are zeroed   (:175-185; train-time augmentation, host-drawn span)
+template <typename T, bool XF>
 __global__ __launch_bounds__(256) void patch_gather_kernel(const float *__restrict__ x, T *__restrict__ out, int C, int L,
-                                                           int P, int n, int PB, int64_t ld) {
+                                                           int P, int n, int PB, int64_t ld, int L_raw,
+                                                           const float *__restrict__ mean, const float *__restrict__ inv_std,
+                                                           const int *__restrict__ t0, const int *__restrict__ tlen) {
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [C][W+1]
     const int b = blockIdx.y, p0 = blockIdx.x * PB;
     const int np = min(PB, n - p0), W = np * P, WS = PB * P + 1;
-    const float *xb = x + (int64_t)b * C * L + (int64_t)p0 * P;
+    const int Lsrc = XF ? L_raw : L;
+    const float *xb = x + (int64_t)b * C * Lsrc + (int64_t)p0 * P;
+    int z0 = 0, z1 = 0;
+    if (XF && t0) { z0 = t0[b]; z1 = z0 + tlen[b]; }
     for (int idx = threadIdx.x; idx < C * W; idx += 256) {
         const int c = idx / W, s = idx - c * W;
-        tile[c * WS + s] = xb[(int64_t)c * L + s];
+        float v;
+        if (XF) {
+            const int pos = p0 * P + s;
+            v = 0.f;
+            if (pos < L_raw && !(pos >= z0 && pos < z1)) v = (xb[(int64_t)c * Lsrc + s] - mean[c]) * inv_std[c];
+        } else {
+            v = xb[(int64_t)c * L + s];
+        }
+        tile[c * WS + s] = v;
     }
     __syncthreads();
     const int CP = C * P;
@@ -371,21 +389,33 @@ inline int grid_for_rows(int64_t rows) { return (int)std::min<int64_t>((rows + 3
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-int ecgvit_patch_gather(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream) {
+static int patch_gather_launch(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream, bool xf,
+                               int L_raw, const float *mean, const float *inv_std, const int *t0, const int *tlen) {
     if (B <= 0 || C <= 0 || P <= 0 || L <= 0 || L % P != 0 || ld < (int64_t)C * P) return ECGVIT_EINVAL;
+    if (xf && (!mean || !inv_std || L_raw <= 0 || L_raw > L || ((t0 == nullptr) != (tlen == nullptr)))) return ECGVIT_EINVAL;
     const int n = L / P;
     int PB = std::max(1, 256 / P);
     while (PB > 1 && (size_t)C * (PB * P + 1) * 4 > 48 * 1024) PB >>= 1;
     const size_t lds = (size_t)C * (PB * P + 1) * 4;
     if (lds > 64 * 1024) return ECGVIT_EINVAL;
     dim3 grid((n + PB - 1) / PB, B);
-    if (dtype == ECGVIT_F32)
-        hipLaunchKernelGGL(patch_gather_kernel<float>, grid, dim3(256), lds, as_stream(stream), x, (float *)patches, C, L, P, n, PB, ld);
-    else if (dtype == ECGVIT_BF16)
-        hipLaunchKernelGGL(patch_gather_kernel<bf16_t>, grid, dim3(256), lds, as_stream(stream), x, (bf16_t *)patches, C, L, P, n, PB, ld);
-    else return ECGVIT_EINVAL;
+    if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
+#define PG(T, X) hipLaunchKernelGGL((patch_gather_kernel<T, X>), grid, dim3(256), lds, as_stream(stream), x, (T *)patches, C, L, P, n, PB, ld, L_raw, mean, inv_std, t0, tlen)
+    if (dtype == ECGVIT_F32) { if (xf) PG(float, true); else PG(float, false); }
+    else { if (xf) PG(bf16_t, true); else PG(bf16_t, false); }
+#undef PG
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
+}
+
+int ecgvit_patch_gather(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream) {
+    return patch_gather_launch(x, patches, B, C, L, P, ld, dtype, stream, false, L, nullptr, nullptr, nullptr, nullptr);
+}
+
+int ecgvit_patch_gather_transform(const float *x_raw, void *patches, int B, int C, int L_raw, int L, int P, int64_t ld,
+                                  const float *mean, const float *inv_std, const int32_t *timeout_start, const int32_t *timeout_len,
+                                  int dtype, void *stream) {
+    return patch_gather_launch(x_raw, patches, B, C, L, P, ld, dtype, stream, true, L_raw, mean, inv_std, timeout_start, timeout_len);
 }
 
 int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, void *X, int B, int n, int d, float dropout_p,

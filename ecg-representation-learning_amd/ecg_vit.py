@@ -329,6 +329,7 @@ class EcgVit(nn.Module):
                 self._wlow = torch.empty(self._layout.total, dtype=torch.bfloat16, device=self._pflat.device)
                 self._wlow_version = -1
             self._eng.bind(self._pflat, self._gflat, self._wlow)
+            self._eng.input_transform = getattr(self, '_input_transform', None)
         if self.compute_dtype == torch.bfloat16:
             self.refresh_low_precision_weights()
         return self._eng
@@ -341,6 +342,13 @@ class EcgVit(nn.Module):
             hip.check(hip.lib().ecgvit_cast_f32_to_bf16(self._pflat.data_ptr(), self._wlow.data_ptr(), self._layout.total,
                                                         hip.stream()), 'cast_f32_to_bf16')
             self._wlow_version = ver
+
+    def set_input_transform(self, transform):
+        """f2: give the model RAW records; Normalize / TimeEndPad / TimeOut run fused inside the patch-embed load
+        (`transform.FusedInputTransform`). `config.max_signal_length` must be the padded length. None restores the default."""
+        self._input_transform = transform
+        self._eng = None
+        return self
 
     def set_compute_dtype(self, dtype):
         self.compute_dtype = dtype

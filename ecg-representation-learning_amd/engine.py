@@ -98,6 +98,7 @@ class VitEngine:
         self.P32 = self.G32 = self.W = None
         self._ws = {}
         self.saved = None
+        self.input_transform = None  # FusedInputTransform: forward() then takes RAW (B, C, L_raw) records
         self.on_grads_ready = None   # callback(tag): a gradient bucket ('head' | 'layer{i}' | 'embed' | 'pretrain') is final
 
     # ---------------------------------------------------------------- buffers
@@ -184,8 +185,18 @@ class VitEngine:
     def _patch_embed(self, x, B):
         a, W, T = self.act, self.W, hip.code(self.dtype)
         pre = 'vit.'
-        # a4: patch Rearrange (integer gather) + Linear(C*P, d)
-        check(lib().ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, stream()), 'patch_gather')
+        # a4: patch Rearrange (integer gather) + Linear(C*P, d)   [+ f2: Normalize / TimeEndPad / TimeOut fused into the load]
+        xf = self.input_transform
+        if xf is not None:
+            mean, inv_std = xf.device_stats(x.device)
+            t0 = tl = None
+            if xf.timeout and self.saved is not None and self.saved.get('training', True):
+                t0, tl = xf.draw_timeout(B, self.L, x.device)
+            self._xf_keep = (mean, inv_std, t0, tl)   # keep the int32 spans alive until the kernel has run
+            check(lib().ecgvit_patch_gather_transform(ptr(x), ptr(a['patches']), B, self.C, x.shape[2], self.L, self.P, self.CP, ptr(mean),
+                                                      ptr(inv_std), ptr(t0), ptr(tl), T, stream()), 'patch_gather_transform')
+        else:
+            check(lib().ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, stream()), 'patch_gather')
         hip.gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], B * self.n, self.d, self.CP, self.CP,
                  self.CP, self.d, epilogue=EPI_BIAS, bias=self.P32[pre + 'to_patch_embedding.1.bias'])
 
@@ -225,14 +236,18 @@ class VitEngine:
     def forward(self, x, labels=None, weight=None, training=True, seed=0, want_mean=True):
         """x: (B, C, L) f32 contiguous device tensor. Returns (logits (B,K) f32, loss_elem (B,K) f32 | None, loss_mean (1,) | None)."""
         B = x.shape[0]
-        assert x.shape[1] == self.C and x.shape[2] == self.L and x.dtype == torch.float32 and x.is_contiguous()
+        assert x.shape[1] == self.C and x.dtype == torch.float32 and x.is_contiguous()
+        if self.input_transform is None:
+            assert x.shape[2] == self.L
+        else:
+            assert self.input_transform.padded_length(x.shape[2]) == self.L, 'config.max_signal_length must be the padded length'
         self._alloc(B)
         a, T = self.act, hip.code(self.dtype)
         l, st = lib(), stream()
         d, N, n = self.d, self.N, self.n
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
-        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False)
+        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False, training=training)
         pre = 'vit.'
         self._patch_embed(x, B)
         # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout

@@ -46,6 +46,7 @@ SIGNATURES = {
     'ecgvit_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'ecgvit_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
     'ecgvit_patch_gather': (c_int, [_P, _P, _I, _I, _I, _I, _L, _I, _P]),
+    'ecgvit_patch_gather_transform': (c_int, [_P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _I, _P]),
     'ecgvit_embed_finish': (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _U, _I, _P]),
     'ecgvit_embed_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _U, _I, _P]),
     'ecgvit_layernorm_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),

@@ -92,6 +92,13 @@ int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d);
  * ------------------------------------------------------------------------------------------------ */
 /* patches[(b*n + p) * ld + j*C + c] = x[b][c][p*P + j]; columns [C*P, ld) are zero-filled. x is f32. */
 int ecgvit_patch_gather(const float *x, void *patches, int B, int C, int L, int P, int64_t ld, int dtype, void *stream);
+/* Same gather with the reference's input transforms fused into the load (next row f2; preprocess/transform.py:18-35 Normalize,
+ * :140-154 TimeEndPad, :175-185 TimeOut; wired at preprocess/ptb_dataset.py:132-149): x_raw is (B, C, L_raw) f32,
+ * value(b,c,s) = s < L_raw and s not in [timeout_start[b], +timeout_len[b]) ? (x_raw - mean[c]) * inv_std[c] : 0, for s < L = n*P.
+ * timeout_start / timeout_len: int32 [B] or both NULL (eval: no TimeOut). */
+int ecgvit_patch_gather_transform(const float *x_raw, void *patches, int B, int C, int L_raw, int L, int P, int64_t ld,
+                                  const float *mean, const float *inv_std, const int32_t *timeout_start,
+                                  const int32_t *timeout_len, int dtype, void *stream);
 /* X[b*N + 0] = cls + pos[0];  X[b*N + 1 + p] = tok[b*n + p] + pos[1 + p]   (N = n + 1; ViT.forward: cat CLS, += pos)
  * optional embedding dropout (p = emb_dropout_p, mask = f(seed, element index in X)). cls/pos are f32. */
 int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, void *X, int B, int n, int d,

@@ -377,3 +377,59 @@ def test_two_rank_data_parallel_step_equals_full_batch(tmp_path, overlap):
     assert abs(ts.grad_norm() - r0['norm']) / r0['norm'] < 1e-4    # clip norm computed on the REDUCED gradient
     assert max_err(m._pflat, r0['p']) < 5e-6
     assert abs(0.5 * (r0['losses'][1] + r1['losses'][1]) - float(loss)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------------ f2: fused input transforms
+def test_fused_input_transforms_match_reference_pipeline():
+    """Normalize + TimeEndPad (+ TimeOut) fused into the patch gather == the reference's host pipeline (golden transforms.npz
+    holds the outputs of the reference's own Normalize / TimeEndPad incl. the full-extra-patch quirk when L % k == 0)"""
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'transforms.npz'))
+    sig, mean, std = z['sig'], z['norm_mean'], z['norm_std']          # (2, 12, 50)
+    xf = E.FusedInputTransform(mean, std, patch_size=25)
+    assert xf.padded_length(50) == 75 and E.FusedInputTransform(mean, std, 20).padded_length(50) == 60   # quirk + plain case
+    from ecg_representation_learning_amd import hip as H
+    for k in (20, 25, 64):
+        xf = E.FusedInputTransform(mean, std, patch_size=k)
+        L = xf.padded_length(50)
+        ref = np.pad((sig - mean.reshape(1, -1, 1)) / std.reshape(1, -1, 1), [(0, 0), (0, 0), (0, L - 50)])   # Normalize then pad
+        assert ref.shape[-1] == z[f'pad_k{k}'].shape[-1]               # the reference's TimeEndPad output length
+        np.testing.assert_array_equal(z[f'pad_k{k}'][..., :50], sig)
+        np.testing.assert_allclose(ref[..., :50], z['norm_out'], rtol=1e-6)
+        if k == 25:   # C*P = 300 is no multiple of 8: not a model shape, but the C-ABI kernel itself takes it (f32 patches)
+            x, mu, isd = torch.from_numpy(sig).cuda(), torch.from_numpy(mean).cuda(), (1.0 / torch.from_numpy(std)).cuda()
+            out = torch.empty(2 * (L // k), k * 12, device='cuda')
+            assert H.lib().ecgvit_patch_gather_transform(x.data_ptr(), out.data_ptr(), 2, 12, 50, L, k, k * 12, mu.data_ptr(), isd.data_ptr(),
+                                                         None, None, H.F32, H.stream()) == 0
+            np.testing.assert_allclose(out.cpu().numpy().reshape(2, L // k, k * 12), O.patch_gather_np(ref.astype(np.float32), k),
+                                       rtol=1e-5, atol=1e-6)
+            continue
+        conf = E.EcgVitConfig(max_signal_length=L, patch_size=k, hidden_size=32, num_hidden_layers=1, num_attention_heads=2,
+                              intermediate_size=64, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+        m = E.EcgVit(config=conf).cuda().eval()
+        m.set_input_transform(xf)
+        eng = m._engine()
+        with torch.no_grad():
+            m(sample_values=torch.from_numpy(sig).cuda())
+        got = eng.act['patches'].float().cpu().numpy().reshape(2, L // k, k * 12)
+        want = O.patch_gather_np(ref.astype(np.float32), k)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    # TimeOut: seeded host draw, zeroed span, same RNG calls as the reference's TimeOut.__call__
+    xf = E.FusedInputTransform(mean, std, patch_size=20, timeout=True)
+    L = xf.padded_length(50)
+    conf = E.EcgVitConfig(max_signal_length=L, patch_size=20, hidden_size=32, num_hidden_layers=1, num_attention_heads=2,
+                          intermediate_size=64, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    m = E.EcgVit(config=conf).cuda().train()
+    m.set_input_transform(xf)
+    eng = m._engine()
+    torch.manual_seed(5)
+    m(sample_values=torch.from_numpy(sig).cuda())
+    got = eng.act['patches'].float().cpu().numpy().reshape(2, L // 20, 240)
+    torch.manual_seed(5)
+    ref = np.pad((sig - mean.reshape(1, -1, 1)) / std.reshape(1, -1, 1), [(0, 0), (0, 0), (0, L - 50)]).astype(np.float32)
+    sampler = torch.distributions.Uniform(low=0.0, high=0.5)
+    for b in range(2):
+        r = sampler.sample().item()
+        l_crop = round(r * L)
+        st = torch.randint(high=L - l_crop, size=(1,)).item()
+        ref[b, :, st:st + l_crop] = 0
+    np.testing.assert_allclose(got, O.patch_gather_np(ref, 20), rtol=1e-5, atol=1e-6)
