@@ -9,8 +9,9 @@ from .check_args import ca, CheckArg
 from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT, MaskedEcgVit
 from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
 from .transform import FusedInputTransform
+from .metrics import get_accuracy, eval_counts, HipEvaluator
 from . import hip
 from . import ddp
 
 __all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'get_train_args', 'lr_multiplier',
-           'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'hip', 'ddp']
+           'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'get_accuracy', 'eval_counts', 'HipEvaluator', 'hip', 'ddp']

@@ -212,6 +212,17 @@ int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, vo
                            int64_t rows, int width, int64_t ld, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * evaluation metrics (next row f1).  replaces: get_accuracy (ecg_transformer/util/train.py:12-56), called on every train
+ * step (models/train.py:289) and after each eval pass (models/train.py:371) -- there a D2H copy of the logits + sklearn.
+ * scores / labels: (B, K) f32 with row pitches ld_*; scores are probabilities, or logits when from_logits != 0 (then the f32
+ * sigmoid the reference applies first, models/train.py:369, is evaluated in the kernel).  counts: uint64 [4 + 2K], overwritten:
+ *   [0..3] tp, tn, fp, fn of (prob >= 0.5) over all B*K;  [4 + c] positives of class c;
+ *   [4 + K + c] sum over (positive i, negative j) of 2*[p_i > p_j] + [p_i == p_j]  (AUROC_c = that / (2 P_c N_c)); 0 unless with_auc.
+ * ------------------------------------------------------------------------------------------------ */
+int ecgvit_eval_counts(const float *scores, int64_t ld_scores, const float *labels, int64_t ld_labels, int64_t B, int K, int from_logits,
+                       int with_auc, uint64_t *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * probes used by tests to pin hardware fragment layouts with exact integer data
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_probe_mfma_layout(float *out /* [4][64][16] */, void *stream);

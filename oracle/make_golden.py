@@ -88,9 +88,40 @@ def _np(t):
     return t.detach().cpu().numpy().copy()  # copy: later in-place optimiser steps must not alias saved arrays
 
 
+def metrics_golden():
+    """(12) eval metrics ("next" row f1): the reference's own `get_accuracy` (util/train.py:12-56, sklearn underneath) run on
+    seeded probabilities / multi-hot labels: ties, absent classes, the all-rows-equal case (no AUROC), a single valid class"""
+    ref_train_util = importlib.import_module('ecg_transformer.util.train')
+    rng = np.random.default_rng(77)
+    cases = {}
+
+    def case(name, probs, labels):
+        out = ref_train_util.get_accuracy(torch.from_numpy(probs), torch.from_numpy(labels), return_auc=True)
+        cases[name] = dict(
+            probs=probs.tolist(), labels=labels.tolist(),
+            expect={k: (None if v is None else ({kk: float(vv) for kk, vv in v.items()} if isinstance(v, dict) else float(v)))
+                    for k, v in out.items()})
+    K = 71
+    prior = np.concatenate([np.full(8, 0.3), np.full(23, 0.05), np.full(40, 0.004)])        # PTB-XL-like: most codes are rare
+    lb = (rng.random((96, K)) < prior).astype(np.float32)
+    pr = np.clip(0.35 * lb + rng.random((96, K)) * 0.7, 0, 1).astype(np.float32)
+    case('b96_rare', pr, lb)
+    case('b96_ties', (np.round(pr * 8) / 8).astype(np.float32), lb)                          # heavy ties incl. exactly 0.5
+    lb1 = np.tile(lb[:1], (8, 1))
+    case('b8_rows_equal', pr[:8].copy(), lb1)                                                 # msk_2_class empty: macro_auc None
+    lb2 = lb1.copy(); lb2[3, 5] = 1 - lb2[3, 5]
+    case('b8_one_class', pr[:8].copy(), lb2)                                                  # roc_auc_score returns a scalar
+    case('b4_all_neg_pred', np.full((4, K), 0.1, np.float32), lb[:4].copy())                  # zero_division branches
+    with open(os.path.join(OUT, 'metrics.json'), 'w') as f:
+        json.dump(dict(id2code=list(ref_train_util.get_accuracy.id2code), cases=cases), f)
+    print('metrics:', {k: (v['expect']['binary_accuracy'], v['expect']['macro_auc']) for k, v in cases.items()})
+
+
 def main():
     _install_stubs()
     sys.path.insert(0, REF)
+    if '--only-metrics' in sys.argv:
+        return metrics_golden()
     ecg_vit = importlib.import_module('ecg_transformer.models.ecg_vit')
     ref_train = importlib.import_module('ecg_transformer.models.train')
     ref_util = importlib.import_module('ecg_transformer.util')
@@ -273,6 +304,7 @@ def main():
     pads['norm_out'] = transform.Normalize(**stats)(sig)
     pads['sig'] = sig
     np.savez_compressed(os.path.join(OUT, 'transforms.npz'), **pads)
+    metrics_golden()
     print('wrote', sorted(os.listdir(OUT)))
 
 

@@ -433,3 +433,28 @@ def test_fused_input_transforms_match_reference_pipeline():
         st = torch.randint(high=L - l_crop, size=(1,)).item()
         ref[b, :, st:st + l_crop] = 0
     np.testing.assert_allclose(got, O.patch_gather_np(ref, 20), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------ f1: evaluate on device
+def test_evaluator_matches_oracle_eval_pass():
+    """HipEvaluator (MyTrainer.evaluate on the device) vs the oracle model + oracle metrics on the same weights and records"""
+    from oracle.metrics_oracle import get_accuracy_np
+    kw = dict(max_signal_length=2560, patch_size=64, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128)
+    conf, om, m, x, y = _oracle_pair(kw, 24, F32)
+    ev = E.HipEvaluator(m, eval_batch_size=10)                          # ragged last batch (10, 10, 4)
+    m.train()
+    out = ev.evaluate(x.cuda(), y.cuda(), return_predictions=True)
+    assert m.training                                                   # mode restored, as the reference does
+    om.eval()
+    with torch.no_grad():
+        outs = [om(sample_values=x[s:s + 10], labels=y[s:s + 10]) for s in range(0, 24, 10)]
+    lo, loss = torch.cat([o.logits for o in outs]), float(np.mean([float(o.loss) for o in outs]))
+    assert max_err(out['predictions']['logits'], lo) < 1e-4
+    want = get_accuracy_np(torch.sigmoid(out['predictions']['logits']).cpu().numpy(), y.numpy())
+    d = out['metrics']
+    assert abs(d['eval/loss'] - loss) / loss < 1e-5
+    for k in ('binary_accuracy', 'weighted_binary_accuracy', 'binary_negative_recall', 'binary_positive_recall'):
+        assert abs(d[f'eval/{k}'] - want[k]) < 1e-12
+    assert (d['eval/macro_auc'] is None) == (want['macro_auc'] is None)
+    if want['macro_auc'] is not None:
+        assert abs(d['eval/macro_auc'] - want['macro_auc']) < 1e-6      # in-kernel f32 sigmoid vs torch's: tie structure only

@@ -534,3 +534,63 @@ def test_gemm_bf16_large_shapes(layout, shape):
                  residual=dev(res), ldr=N)
         assert torch.isfinite(C.float()).all()
         assert rel_err(C, ref + bias.double() + res.double()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------------ f1: evaluation metrics
+def _metrics_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.json')) as f:
+        return json.load(f)
+
+
+def test_eval_counts_bit_exact_and_get_accuracy_matches_reference():
+    import ecg_representation_learning_amd as E
+    from oracle.metrics_oracle import eval_counts_np
+    g = _metrics_golden()
+    for name, case in g['cases'].items():
+        probs, labels = np.asarray(case['probs'], np.float32), np.asarray(case['labels'], np.float32)
+        h = E.eval_counts(torch.from_numpy(probs).cuda(), torch.from_numpy(labels).cuda(), id2code=g['id2code'])
+        np.testing.assert_array_equal(h.counts.cpu().numpy(), eval_counts_np(probs, labels), err_msg=name)   # integers: bit-exact
+        got, want = h.result(), case['expect']
+        for k, v in want.items():
+            if v is None:
+                assert got[k] is None, (name, k)
+            elif isinstance(v, dict):
+                assert list(got[k]) == list(v)
+                assert max(abs(got[k][c] - a) for c, a in v.items()) < 1e-12, name
+            else:
+                assert abs(got[k] - v) < 1e-12, (name, k)
+        no_auc = E.get_accuracy(torch.from_numpy(probs).cuda(), torch.from_numpy(labels).cuda(), return_auc=False)
+        assert no_auc['macro_auc'] is None and no_auc['per_class_auc'] is None and no_auc['binary_accuracy'] == got['binary_accuracy']
+
+
+def test_eval_counts_eval_set_size_rank_identity():
+    """whole-eval-set size (PTB-XL test fold ~ 2.2k; here 20k x 71, ragged vs the 256 / 2048 tiles): the pair counts must equal the
+    Mann-Whitney statistic from average ranks (O(B log B) on the host), and logits input == probabilities input"""
+    import ecg_representation_learning_amd as E
+    from scipy.stats import rankdata
+    rng = np.random.default_rng(3)
+    B, K = 20011, 71
+    prior = np.concatenate([np.full(8, 0.3), np.full(23, 0.05), np.full(40, 0.002)])
+    lb = (rng.random((B, K)) < prior).astype(np.float32)
+    logit = (rng.standard_normal((B, K)) + 1.5 * lb - 2).astype(np.float32)
+    logit = np.round(logit * 64) / 64                                  # ties
+    prob = torch.sigmoid(torch.from_numpy(logit).cuda())
+    h = E.eval_counts(prob, torch.from_numpy(lb).cuda())
+    cnt = h.counts.cpu().numpy()
+    p = prob.cpu().numpy()
+    for c in range(K):
+        y = lb[:, c] != 0
+        P, N = int(y.sum()), int((~y).sum())
+        assert cnt[4 + c] == P
+        r = rankdata(p[:, c])                                            # average ranks, halves exact in f64
+        u2 = int(round(2 * (r[y].sum() - P * (P + 1) / 2)))
+        assert cnt[4 + K + c] == u2, c
+    pred, yy = p >= 0.5, lb != 0
+    assert cnt[0] == (pred & yy).sum() and cnt[1] == (~pred & ~yy).sum() and cnt[2] == (pred & ~yy).sum() and cnt[3] == (~pred & yy).sum()
+    h2 = E.eval_counts(torch.from_numpy(logit).cuda(), torch.from_numpy(lb).cuda(), from_logits=True)
+    c2 = h2.counts.cpu().numpy()
+    np.testing.assert_array_equal(c2[:4 + K], cnt[:4 + K])
+    # in-kernel f32 sigmoid vs torch's: tie structure of saturated values may differ by a few pairs at most
+    assert np.max(np.abs(c2[4 + K:] - cnt[4 + K:]) / np.maximum(cnt[4 + K:], 1)) < 1e-5

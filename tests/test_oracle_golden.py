@@ -116,3 +116,27 @@ def test_masked_objective_oracle_runs_and_indexing():
     assert out.logits.shape == (3, 5, 240) and out.loss.ndim == 0
     out.loss.backward()
     assert mm.mask_token.grad is not None and enc.vit.cls_token.grad is None  # no CLS in the masked trunk
+
+
+# ------------------------------------------------------------------------------------------------------ f1: evaluation metrics
+def test_metrics_oracle_matches_reference_get_accuracy():
+    """oracle/metrics_oracle.py vs outputs of the reference's own get_accuracy (sklearn underneath), incl. its swapped recalls,
+    the no-valid-class case (macro_auc None) and the single-valid-class case"""
+    import json
+    from oracle.metrics_oracle import get_accuracy_np
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'metrics.json')) as f:
+        g = json.load(f)
+    assert len(g['id2code']) == 71 and len(g['cases']) >= 5
+    for name, case in g['cases'].items():
+        got = get_accuracy_np(np.asarray(case['probs'], np.float32), np.asarray(case['labels'], np.float32), id2code=g['id2code'])
+        want = case['expect']
+        assert set(got) == set(want)
+        for k, v in want.items():
+            if v is None:
+                assert got[k] is None, (name, k)
+            elif isinstance(v, dict):
+                assert list(got[k]) == list(v), (name, k)            # same classes, same order
+                for code, auc in v.items():
+                    assert abs(got[k][code] - auc) < 1e-12, (name, code)
+            else:
+                assert abs(got[k] - v) < 1e-12, (name, k, got[k], v)
