@@ -6,12 +6,12 @@ ModelOutput(loss, logits)` / train-step surface, executed by hand-written HIP ke
 fails loudly when the HIP library is absent (no CPU / eager fallback by design).
 """
 from .check_args import ca, CheckArg
-from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT, MaskedEcgVit
+from .ecg_vit import EcgVitConfig, EcgVit, ModelOutput, HipViT, MaskedEcgVit, load_trained
 from .train import get_train_args, lr_multiplier, HipTrainStep, clip_grad_norm_
 from .transform import FusedInputTransform
 from .metrics import get_accuracy, eval_counts, HipEvaluator
 from . import hip
 from . import ddp
 
-__all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'get_train_args', 'lr_multiplier',
+__all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'load_trained', 'get_train_args', 'lr_multiplier',
            'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'get_accuracy', 'eval_counts', 'HipEvaluator', 'hip', 'ddp']

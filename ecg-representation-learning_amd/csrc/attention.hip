@@ -471,9 +471,40 @@ __global__ __launch_bounds__(64) void probe_kernel(float *out) {
     }
 }
 
+
+// ---- export of the post-softmax probabilities of the fused path (next row f3): P[bh][q][k] = exp(scale * q.k - lse[bh][q]), rebuilt from
+//      the qkv and log-sum-exp the fused forward already keeps for backward. Visualisation-time only (vit_pytorch Recorder, reference
+//      ecg_vit.py:176-180), so a plain VALU kernel: one wave per query row, lanes over keys, f32 accumulation of the bf16 products.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t *__restrict__ qkv, const float *__restrict__ lse, float *__restrict__ probs,
+                                                         int N, int h, int dh, float scale) {
+    const int bh = blockIdx.y, b = bh / h, head = bh % h;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= N) return;
+    const int64_t ld = 3 * (int64_t)h * dh;
+    const bf16_t *qrow = qkv + ((int64_t)b * N + q) * ld + head * dh;
+    const float l = lse[(int64_t)bh * N + q];
+    for (int k = lane; k < N; k += 64) {
+        const bf16_t *krow = qkv + ((int64_t)b * N + k) * ld + (int64_t)h * dh + head * dh;
+        float acc = 0.f;
+        for (int e = 0; e < dh; e += 8) {
+            const Vec16<bf16_t> a = ld16(qrow + e), c = ld16(krow + e);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = fmaf(a.get(t), c.get(t), acc);
+        }
+        probs[((int64_t)bh * N + q) * N + k] = expf(acc * scale - l);
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int ecgvit_attention_probs(const void *qkv, const float *lse, float *probs, int B, int N, int h, int dh, float scale, int dtype, void *stream) {
+    if (dtype != ECGVIT_BF16 || dh % 8 || B <= 0 || N <= 0 || h <= 0 || (int64_t)B * h > 65535) return ECGVIT_EINVAL;
+    hipLaunchKernelGGL(attn_probs_kernel, dim3((N + 3) / 4, B * h), dim3(256), 0, as_stream(stream), (const bf16_t *)qkv, lse, probs, N, h, dh, scale);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
 
 int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
                          uint64_t seed, int dtype, void *stream) {

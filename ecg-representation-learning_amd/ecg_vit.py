@@ -371,6 +371,40 @@ class EcgVit(nn.Module):
     def attention_probs(self, layer):
         return self._engine().attention_probs(layer).clone()
 
+    def attention_rollout(self, sample_values):
+        """The attention map `EcgVitVisualizer.__call__` derives (reference ecg_vit.py:176-194) for ONE (12, L) record: per-layer
+        head-averaged attention + identity, row-normalised, multiplied with the layer below, CLS row, scaled by the global maximum.
+        Returns (logits (K,), map (layers, n_patch)) as device tensors; plotting stays with the caller."""
+        assert sample_values.dim() == 2 and sample_values.size(0) == self.config.num_channels
+        was = self.training
+        self.eval()
+        with torch.no_grad():
+            logits = self(sample_values=sample_values.unsqueeze(0).contiguous()).logits[0]
+            attn = torch.stack([self._engine().attention_probs(i)[0].mean(dim=0) for i in range(self.config.num_hidden_layers)])
+            attn = attn + torch.eye(attn.size(1), device=attn.device)
+            attn = attn / attn.sum(dim=-1, keepdim=True)
+            res = torch.empty_like(attn)
+            res[0] = attn[0]
+            for i in range(1, attn.size(0)):
+                res[i] = attn[i] @ attn[i - 1]
+            res = res[:, 0, 1:]
+            res = res / res.max()
+        self.train(was)
+        return logits, res
+
+
+def load_trained(model_key='ecg-vit-base', checkpoint_path=None, compute_dtype=torch.float32):
+    """`load_trained` of the reference (ecg_vit.py:150-161): build the named config, `torch.load` the `.pt` state_dict the reference's
+    trainer wrote (`torch.save(model.state_dict())`, models/train.py:297-300, :319), STRICT load, eval mode. The reference hard-codes
+    the path of its own run; here it is an argument."""
+    if checkpoint_path is None:
+        raise ValueError('checkpoint_path is required (the reference hard-codes a path inside its own model directory)')
+    model = EcgVit(config=EcgVitConfig.from_defined(model_key), compute_dtype=compute_dtype)
+    ckpt = torch.load(checkpoint_path, map_location='cpu')
+    model.load_state_dict(ckpt, strict=True)
+    model.eval()
+    return model
+
 
 # ----------------------------------------------------------------------------------------------------------
 # masked pre-train objective -- NOT in the reference (SURVEY 8 a15): the build's own SimMIM-style definition

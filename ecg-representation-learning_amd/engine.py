@@ -483,8 +483,11 @@ class VitEngine:
     # ---------------------------------------------------------------- per-layer attention probabilities (f3)
     def attention_probs(self, layer):
         """Post-softmax attention of `layer` for the last forward, (B, h, N, N) f32 -- what vit_pytorch's Recorder hooks
-        (reference ecg_vit.py:176-194). f32 engine only (the bf16 path never materialises the scores)."""
-        if self.dtype != torch.float32:
-            raise RuntimeError('attention probabilities are only materialised on the float32 path')
-        B = self.saved['B']
-        return self.act['layers'][layer]['probs'].view(B, self.h, self.T, self.T)
+        (reference ecg_vit.py:176-194). The f32 path keeps them; the fused bf16 path rebuilds them from its saved qkv + log-sum-exp."""
+        B, L = self.saved['B'], self.act['layers'][layer]
+        if self.dtype == torch.float32:
+            return L['probs'].view(B, self.h, self.T, self.T)
+        out = torch.empty(B, self.h, self.T, self.T, dtype=torch.float32, device=L['qkv'].device)
+        check(lib().ecgvit_attention_probs(ptr(L['qkv']), ptr(L['lse']), ptr(out), B, self.T, self.h, self.dh, self.scale, hip.BF16, stream()),
+              'attention_probs')
+        return out

@@ -145,6 +145,11 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
 int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
                          int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
                          void *stream);
+/* export of the fused path's post-softmax probabilities (next row f3; what vit_pytorch's Recorder hooks, reference ecg_vit.py:176-180):
+ * probs[B,h,N,N] f32 = exp(scale * q k^T - lse), from the qkv / lse a fused forward left behind. bf16 path only (the f32 path
+ * materialises the scores anyway); visualisation-time, not tuned. B*h <= 65535. */
+int ecgvit_attention_probs(const void *qkv, const float *lse, float *probs, int B, int N, int h, int dh, float scale, int dtype,
+                           void *stream);
 /* f32 parity path pieces (scores materialised; the GEMMs are ecgvit_gemm batched calls):
  * in-place row softmax of S[rows, ld] over the first N columns; optional export is the buffer itself. */
 int ecgvit_softmax_rows(float *S, int64_t rows, int N, int64_t ld, void *stream);

@@ -458,3 +458,46 @@ def test_evaluator_matches_oracle_eval_pass():
     assert (d['eval/macro_auc'] is None) == (want['macro_auc'] is None)
     if want['macro_auc'] is not None:
         assert abs(d['eval/macro_auc'] - want['macro_auc']) < 1e-6      # in-kernel f32 sigmoid vs torch's: tie structure only
+
+
+# ------------------------------------------------------------------------------------------------------ f3: checkpoints, attention export
+def test_load_trained_reference_checkpoint_and_attention_export(tmp_path):
+    """a `.pt` written the way the reference's trainer writes it (torch.save(state_dict) of the oracle model = reference key layout)
+    loads strictly; the fused bf16 path's exported attention == the f32 path's materialised probabilities (bf16 q/k rounding:
+    5e-3 absolute on probabilities), rows sum to 1, and the visualiser's rollout matches the same arithmetic on the oracle's probabilities"""
+    torch.manual_seed(3)
+    conf = E.EcgVitConfig.from_defined('ecg-vit-tiny')
+    ref = O.OracleEcgVit(config=conf)
+    path = os.path.join(tmp_path, 'model.pt')
+    torch.save(ref.state_dict(), path)
+    bad = {k: v for k, v in ref.state_dict().items() if 'mlp_head' not in k}
+    torch.save(bad, os.path.join(tmp_path, 'bad.pt'))
+    with pytest.raises(RuntimeError):
+        E.load_trained('ecg-vit-tiny', os.path.join(tmp_path, 'bad.pt'))           # strict, like the reference
+    m32 = E.load_trained('ecg-vit-tiny', path).cuda()
+    assert not m32.training
+    x, _ = O.synthetic_batch(2, length=conf.max_signal_length, seed=5)
+    with torch.no_grad():
+        o32 = m32(sample_values=x.cuda())
+    ref.eval()
+    with torch.no_grad():
+        assert max_err(o32.logits, ref(sample_values=x).logits) < 1e-4
+    if True:
+        m16 = E.load_trained('ecg-vit-tiny', path, compute_dtype=BF16).cuda()
+        with torch.no_grad():
+            m16(sample_values=x.cuda())
+        for layer in range(conf.num_hidden_layers):
+            p16, p32 = m16.attention_probs(layer), m32.attention_probs(layer)
+            assert p16.shape == p32.shape
+            assert float((p16.sum(-1) - 1).abs().max()) < 1e-3
+            assert float((p16 - p32).abs().max()) < 5e-3
+    logits, amap = m32.attention_rollout(x[0].cuda())
+    L = conf.num_hidden_layers
+    attn = torch.stack([m32.attention_probs(i)[0].mean(0) for i in range(L)]).cpu()   # probs of the single-record forward it ran
+    attn = attn + torch.eye(attn.size(1))
+    attn = attn / attn.sum(-1, keepdim=True)
+    res = torch.stack([attn[0]] + [attn[i] @ attn[i - 1] for i in range(1, L)])[:, 0, 1:]
+    res = res / res.max()
+    assert amap.shape == (L, conf.max_signal_length // conf.patch_size)
+    assert max_err(amap, res) < 1e-5 and float(amap.max()) == 1.0
+    assert max_err(logits, o32.logits[0]) < 1e-5
