@@ -175,7 +175,8 @@ __device__ __forceinline__ void epi_row8(const f32x4 c0, const f32x4 c1, int64_t
         Vec16<bf16_t> out;
 #pragma unroll
         for (int k = 0; k < 8; ++k) out.set(k, v[k]);
-        st16(o, out);
+        if (sk.ablate & 8) st16(o, out);
+        else __builtin_nontemporal_store(out.v, reinterpret_cast<bf16x8 *>(o));   // streamed once: keep the operand panels in L2
 #pragma unroll
         for (int k = 0; k < 8; ++k) cs[k] += out.get(k);
     } else {
@@ -993,6 +994,262 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pers_kernel(ecgvit_gemm_desc
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Quadrant-phased persistent kernel ("Q", forward layout: both operands K-contiguous, K % 64 == 0, K >= 192).
+//   * v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it than on 32x32x16), wave tile 128 x 64 = 8 x 4 tiles;
+//   * a K-tile is FOUR phases, one 64 x 32 output quadrant x K = 64 each (16 MFMAs = 256 cycles), quadrant order
+//     (top,left) (top,right) (bottom,right) (bottom,left): 12 / 4 / 8 / 0 ds_read_b128 per phase, nothing read twice;
+//   * operands arrive as 16-KiB HALF tiles (128 rows x 64 k), one half-tile DMA (2 instructions per wave) per phase, from
+//     a stream that runs CONTINUOUSLY across output tiles: the A stream (activations: HBM / Infinity Cache misses) two
+//     K-tiles ahead in three ring slots per half, the B stream (weights: L2 hits) one K-tile ahead in two -- 10 x 16 KiB =
+//     all of LDS, up to 96 KiB in flight per CU, ONE counted wait (vmcnt(4)) per K-tile, never a drain;
+//   * waves 4-7 run one barrier behind waves 0-3 (ping-pong on every SIMD) for the whole kernel, epilogues included: a
+//     wave drains its accumulators through a 4-KiB patch inside the A half-tile slot its OWN group just finished reading
+//     (group g reads only A-half g), so no extra barrier and no realignment bubble separates two output tiles.
+constexpr int HALF_BYTES = 16384;
+
+template <typename TO>
+__device__ __forceinline__ void epilogue_store_q(f32x4 (&acc)[8][4], char *patch, const ecgvit_gemm_desc &d, const EpiParams &e,
+                                                 const SplitK2 &sk, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int cq = lane & 7;
+    const int n = n0 + wn * 64 + cq * 8;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * fq + r, col = 16 * j + fr;
+                *reinterpret_cast<float *>(patch + row * 256 + ((((col >> 2) ^ (row & 1)) << 4) | ((col & 3) << 2))) = acc[i][j][r];
+            }
+#pragma unroll 1
+        for (int p = 0; p < 2; ++p) {
+            const int rr = p * 8 + (lane >> 3);
+            const f32x4 c0 = *reinterpret_cast<const f32x4 *>(patch + rr * 256 + (((2 * cq) ^ (rr & 1)) << 4));
+            const f32x4 c1 = *reinterpret_cast<const f32x4 *>(patch + rr * 256 + (((2 * cq + 1) ^ (rr & 1)) << 4));
+            epi_row8<TO>(c0, c1, (int64_t)m0 + wm * 128 + i * 16 + rr, n, d, e, sk, 0, cs);
+        }
+    }
+    epi_colsum_flush(cs, d, e, m0, n, wm, lane);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n,
+                                                             int nitems) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const int M = d.M, N = d.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wm == 1;
+    const int nk = d.K / BK;
+    const int lda2 = (int)d.lda * 2, ldb2 = (int)d.ldb * 2;   // row pitches in bytes
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)M * lda2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
+    // this wave's two DMA pieces of a half-tile: rows 16*wave + {0..7}, {8..15}; source chunk pre-swizzled (image chunk ^= (row>>1)&7)
+    const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8;
+    const int cA0 = ((lane & 7) ^ ((r0 >> 1) & 7)) * 16, cA1 = ((lane & 7) ^ ((r1 >> 1) & 7)) * 16;
+    const int voA0 = r0 * lda2 + cA0, voA1 = r1 * lda2 + cA1;
+    const int voB0 = r0 * ldb2 + cA0, voB1 = r1 * ldb2 + cA1;
+    // fragment read offset inside a half-tile image: row = 16t + (lane&15), chunk = 4s + (lane>>4), swizzled; s = 1 is ^ 64
+    const int fr = lane & 15, fq = lane >> 4;
+    const int loff = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+    const int boff = (wn & 1) * 64 * 128 + loff;
+
+#define Q_DMA_A(h, ring, soff)                                                                                                   \
+    do {                                                                                                                         \
+        char *dst_ = smem + (3 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                       \
+        const int so_ = (soff) + (h) * 128 * lda2;                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst_, 16, voA0, so_, 0, 0);                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dst_ + 1024), 16, voA1, so_, 0, 0);                               \
+    } while (0)
+#define Q_DMA_B(h, ring, soff)                                                                                                   \
+    do {                                                                                                                         \
+        char *dst_ = smem + (6 + 2 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                   \
+        const int so_ = (soff) + (h) * 128 * ldb2;                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst_, 16, voB0, so_, 0, 0);                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst_ + 1024), 16, voB1, so_, 0, 0);                               \
+    } while (0)
+#define Q_PHASE_SYNC_A()                                   \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_setprio(1);                     \
+    } while (0)
+#define Q_PHASE_SYNC_B()                   \
+    do {                                   \
+        __builtin_amdgcn_s_setprio(0);     \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    Item cur = decode_item(it, d, sk, tiles_m, tiles_n), nxt = cur;
+    // producer cursors: byte offset of (tile row, k) in the scalar offset; per-lane offsets never change
+    int a_it = it, a_kt = 0, a_base = cur.m0 * lda2;
+    int b_it = it, b_kt = 0, b_base = cur.n0 * ldb2;
+    bool a_ok = true, b_ok = true;
+#define Q_ADV_A()                                                                     \
+    do {                                                                              \
+        if (++a_kt == nk) {                                                           \
+            a_kt = 0;                                                                 \
+            a_it += (int)gridDim.x;                                                   \
+            if (a_it < nitems) { nxt = decode_item(a_it, d, sk, tiles_m, tiles_n); a_base = nxt.m0 * lda2; } \
+            else a_ok = false;                                                        \
+        }                                                                             \
+    } while (0)
+#define Q_ADV_B()                                                                     \
+    do {                                                                              \
+        if (++b_kt == nk) {                                                           \
+            b_kt = 0;                                                                 \
+            b_it += (int)gridDim.x;                                                   \
+            if (b_it < nitems) b_base = nxt.n0 * ldb2;                                \
+            else b_ok = false;                                                        \
+        }                                                                             \
+    } while (0)
+
+    // ---- prologue: A(0), B(0), A(1)
+    Q_DMA_A(0, 0, a_base); Q_DMA_A(1, 0, a_base); Q_ADV_A();
+    Q_DMA_B(0, 0, b_base); Q_DMA_B(1, 0, b_base); Q_ADV_B();
+    Q_DMA_A(0, 1, a_base + a_kt * (BK * 2)); Q_DMA_A(1, 1, a_base + a_kt * (BK * 2)); Q_ADV_A();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    int ga = 0, gb = 0;   // ring slots of the K-tile being multiplied
+    // diagnostics (ECGVIT_GEMM_ABLATE=4 with a workspace): per block and wave group, s_memtime at tile start / main loop end / epilogue end
+    unsigned long long *stamps = (sk.ablate & 4) ? reinterpret_cast<unsigned long long *>(sk.slabs) : nullptr;
+    int tile_no = 0;
+    // De-phase the CUs: every block walks tiles of identical cost, so without this all 256 CUs reach their epilogues together and
+    // the 32 MB of output stores go out as one HBM-write-bound burst (measured: 10.4k cycles per 128-KiB tile = 6.7 TB/s chip-wide)
+    // while the write path idles during main loops.  Block b starts bitrev8(b)/256 of a tile period late; the offsets persist.
+    if (sk.k_per_split > 0) {
+        const unsigned frac = __builtin_bitreverse32((unsigned)blockIdx.x) >> 24;   // 0..255
+        const long long wait = ((long long)sk.k_per_split * frac) >> 8;
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    for (;;) {
+        if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 0] = __builtin_amdgcn_s_memtime();
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        unsigned long long *fine = (stamps && tile_no == 1 && lane == 0 && (wave & 3) == 0)
+                                       ? stamps + 256 * 2 * 64 * 3 + ((int64_t)blockIdx.x * 2 + wm) * 512 : nullptr;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sa = (3 * wm + ga) * HALF_BYTES + loff;          // byte offsets into smem (kept integral: LDS address space)
+            const int sb = (6 + 2 * (wn >> 1) + gb) * HALF_BYTES + boff;
+            const int ga2 = ga == 0 ? 2 : ga - 1;   // (g + 2) % 3
+            const int gb1 = gb ^ 1;
+            bf16x8 a[4][2], b0[2][2], b1[2][2];
+            // ---------------- phase 1: top-left
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b0[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + j * 2048) ^ (s * 64)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
+            if (b_ok) Q_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+            Q_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[i][j], 0, 0, 0);
+            Q_PHASE_SYNC_B();
+            if (fine && kt < 64) fine[kt * 8 + 0] = __builtin_amdgcn_s_memtime();
+            // ---------------- phase 2: top-right
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + (2 + j) * 2048) ^ (s * 64)));
+            if (b_ok) { Q_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); Q_ADV_B(); }
+            Q_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[i][2 + j], 0, 0, 0);
+            Q_PHASE_SYNC_B();
+            if (fine && kt < 64) fine[kt * 8 + 1] = __builtin_amdgcn_s_memtime();
+            // ---------------- phase 3: bottom-right
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (s * 64)));
+            const bool a_issue = a_ok;
+            if (a_issue) Q_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+            Q_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[4 + i][2 + j], 0, 0, 0);
+            Q_PHASE_SYNC_B();
+            if (fine && kt < 64) fine[kt * 8 + 2] = __builtin_amdgcn_s_memtime();
+            // ---------------- phase 4: bottom-left (no LDS reads); the K-tile's one counted wait: everything but A(kt+2) has landed
+            if (a_issue) {
+                Q_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
+                Q_ADV_A();
+                if (fine && kt < 64) fine[kt * 8 + 4] = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (fine && kt < 64) fine[kt * 8 + 5] = __builtin_amdgcn_s_memtime();
+            Q_PHASE_SYNC_A();
+            if (fine && kt < 64) fine[kt * 8 + 6] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[4 + i][j], 0, 0, 0);
+            Q_PHASE_SYNC_B();
+            if (fine && kt < 64) fine[kt * 8 + 3] = __builtin_amdgcn_s_memtime();
+            ga = ga == 2 ? 0 : ga + 1;
+            gb ^= 1;
+        }
+        // ---------------- output tile done: drain through the A half-tile slot this group just finished with
+        const int next_it = it + (int)gridDim.x;
+        const bool has_next = next_it < nitems;
+        if (!has_next && !late) __builtin_amdgcn_s_barrier();   // the trailing group's last barrier
+        const int gl = ga == 0 ? 2 : ga - 1;
+        if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 1] = __builtin_amdgcn_s_memtime();
+        epilogue_store_q<TO>(acc, smem + (3 * wm + gl) * HALF_BYTES + (wave & 3) * 4096, d, e, sk, cur.m0, cur.n0, wave, lane);
+        if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 2] = __builtin_amdgcn_s_memtime();
+        tile_no = tile_no < 63 ? tile_no + 1 : 63;
+        if (!has_next) break;
+        it = next_it;
+        cur = nxt;
+    }
+#undef Q_DMA_A
+#undef Q_DMA_B
+#undef Q_PHASE_SYNC_A
+#undef Q_PHASE_SYNC_B
+#undef Q_ADV_A
+#undef Q_ADV_B
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
                                                              TO *__restrict__ C, int64_t ldc, EpiParams e) {
@@ -1108,8 +1365,24 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     const int sched = sched_env >= 0 ? sched_env : (d->layout == ECGVIT_GEMM_NT ? 1 : 5);
     const int nitems = ntile * sk.splits;
     // measured: persistence pays for the forward layout (+2..6 %); the whole-tile backward schedule is register-bound (no gain)
-    const bool persist = pers_ok && fast && sched == 1 && d->layout == ECGVIT_GEMM_NT && !sk.ablate;
+    const bool persist = pers_ok && fast && sched == 1 && d->layout == ECGVIT_GEMM_NT && !(sk.ablate & 3);
+    if ((sk.ablate & 4) && d->workspace && d->workspace_bytes >= (256 * 2 * 64 * 3 + 256 * 2 * 512) * 8 && d->layout == ECGVIT_GEMM_NT) sk.slabs = reinterpret_cast<float *>(d->workspace);
+    else sk.ablate &= ~4;
     dim3 pgrid((unsigned)std::min(nitems, 256));
+    static const bool q_ok = [] { const char *e = getenv("ECGVIT_GEMM_Q"); return !(e && e[0] == '0'); }();
+    if (q_ok && sched_env < 0 && persist && d->K % 64 == 0 && d->K >= 192 && sk.splits == 1) {
+        // start stagger in cycles (k_per_split is unused by this kernel): a share of one tile period, only when blocks walk several tiles
+        static const int stag = [] { const char *e = getenv("ECGVIT_GEMM_STAGGER"); return e ? atoi(e) : 100; }();
+        sk.k_per_split = nitems >= 512 ? (int)(((int64_t)(d->K / BK) * 3000 + 8000) * stag / 100) : 0;
+        if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_bf16_q_kernel<bf16_t>, pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems);
+        else hipLaunchKernelGGL(gemm_bf16_q_kernel<float>, pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems);
+        ECGVIT_CHECK_LAUNCH();
+        if (d->epilogue & ECGVIT_EPI_COLSUM) {
+            hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(256), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
+            ECGVIT_CHECK_LAUNCH();
+        }
+        return ECGVIT_OK;
+    }
 #define LAUNCH(AK, BKC, TO)                                                                                              \
     do {                                                                                                                   \
         if (persist && sched == 1) { hipLaunchKernelGGL((gemm_bf16_pers_kernel<AK, BKC, TO, 1>), pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems); break; } \

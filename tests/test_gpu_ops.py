@@ -512,6 +512,7 @@ def test_masked_objective_ops(dtype):
 # ------------------------------------------------------------------------------------------------------ large-shape GEMM variant
 @pytest.mark.parametrize('layout,shape', [
     (hip.GEMM_NT, (4133, 768, 768)), (hip.GEMM_NT, (2048, 264, 240)), (hip.GEMM_NT, (2500, 3072, 768)),
+    (hip.GEMM_NT, (40000, 768, 192)), (hip.GEMM_NT, (33001, 520, 256)), (hip.GEMM_NT, (70000, 1032, 448)),   # > 256 tiles: persistent walk
     (hip.GEMM_NN, (4133, 768, 2304)), (hip.GEMM_NN, (2051, 520, 768)),
     (hip.GEMM_TN, (768, 3072, 9001)), (hip.GEMM_TN, (2304, 768, 4099)), (hip.GEMM_TN, (768, 240, 5000)),
 ])
@@ -534,6 +535,26 @@ def test_gemm_bf16_large_shapes(layout, shape):
                  residual=dev(res), ldr=N)
         assert torch.isfinite(C.float()).all()
         assert rel_err(C, ref + bias.double() + res.double()) < 4e-3
+
+
+def test_gemm_bf16_persistent_forward_is_race_free_and_exact():
+    """the quadrant-phased persistent forward kernel (continuous operand stream across output tiles, counted waits): small-integer
+    operands make every product and sum exact in f32, so the result must EQUAL the integer reference bit for bit, on every one of
+    many repeated launches (a DMA/ds_read race shows up as a sporadically wrong tile), f32 and bf16 outputs, ragged M and N"""
+    g = torch.Generator().manual_seed(5)
+    for (M, N, K) in ((66000, 776, 192), (30011, 2304, 768), (9000, 768, 3072)):
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        B = torch.randint(-3, 4, (N, K), generator=g).float()
+        Ad, Bd = A.to(BF16).cuda(), B.to(BF16).cuda()
+        ref = (Ad.float() @ Bd.float().t())                     # exact: |sum| <= 9 * 3072 < 2^24
+        C = torch.empty(M, N, device='cuda')
+        for rep in range(12):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N)
+            assert torch.equal(C, ref), (M, N, K, rep, int((C != ref).sum()))
+        Cb = torch.empty(M, N, device='cuda', dtype=BF16)
+        hip.gemm(hip.GEMM_NT, Ad, Bd, Cb, M, N, K, K, K, N)
+        assert torch.equal(Cb, ref.to(BF16))
 
 
 # ------------------------------------------------------------------------------------------------------ f1: evaluation metrics

@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--m', type=int, default=512 * 251)
+    ap.add_argument('--library', action='store_true', help='also time torch.matmul (hipBLASLt) on the same shapes: a yardstick only')
     args = ap.parse_args()
     M = args.m
     d, f = 768, 3072
@@ -34,6 +35,13 @@ def main():
             'dgrad NN': lambda: hip.gemm(hip.GEMM_NN, dY, W, dX, M, kin, nout, nout, kin, kin),
             'wgrad TN': lambda: hip.gemm(hip.GEMM_TN, dY, X, dW, nout, kin, M, nout, kin, kin, workspace=ws),
         }
+        if args.library:
+            dWl = torch.empty(nout, kin, device='cuda', dtype=bf)
+            runs.update({
+                'lib NT': lambda: torch.matmul(X, W.t(), out=Y),
+                'lib NN': lambda: torch.matmul(dY, W, out=dX),
+                'lib TN': lambda: torch.matmul(dY.t(), X, out=dWl),
+            })
         for tag, fn in runs.items():
             for _ in range(3):
                 fn()
