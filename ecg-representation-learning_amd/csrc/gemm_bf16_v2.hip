@@ -175,8 +175,7 @@ __device__ __forceinline__ void epi_row8(const f32x4 c0, const f32x4 c1, int64_t
         Vec16<bf16_t> out;
 #pragma unroll
         for (int k = 0; k < 8; ++k) out.set(k, v[k]);
-        if (sk.ablate & 8) st16(o, out);
-        else __builtin_nontemporal_store(out.v, reinterpret_cast<bf16x8 *>(o));   // streamed once: keep the operand panels in L2
+        st16(o, out);
 #pragma unroll
         for (int k = 0; k < 8; ++k) cs[k] += out.get(k);
     } else {
@@ -1129,15 +1128,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
     // diagnostics (ECGVIT_GEMM_ABLATE=4 with a workspace): per block and wave group, s_memtime at tile start / main loop end / epilogue end
     unsigned long long *stamps = (sk.ablate & 4) ? reinterpret_cast<unsigned long long *>(sk.slabs) : nullptr;
     int tile_no = 0;
-    // De-phase the CUs: every block walks tiles of identical cost, so without this all 256 CUs reach their epilogues together and
-    // the 32 MB of output stores go out as one HBM-write-bound burst (measured: 10.4k cycles per 128-KiB tile = 6.7 TB/s chip-wide)
-    // while the write path idles during main loops.  Block b starts bitrev8(b)/256 of a tile period late; the offsets persist.
-    if (sk.k_per_split > 0) {
-        const unsigned frac = __builtin_bitreverse32((unsigned)blockIdx.x) >> 24;   // 0..255
-        const long long wait = ((long long)sk.k_per_split * frac) >> 8;
-        const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-        while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     for (;;) {
         if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 0] = __builtin_amdgcn_s_memtime();
         f32x4 acc[8][4];
@@ -1147,8 +1137,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        unsigned long long *fine = (stamps && tile_no == 1 && lane == 0 && (wave & 3) == 0)
-                                       ? stamps + 256 * 2 * 64 * 3 + ((int64_t)blockIdx.x * 2 + wm) * 512 : nullptr;
         for (int kt = 0; kt < nk; ++kt) {
             const int sa = (3 * wm + ga) * HALF_BYTES + loff;          // byte offsets into smem (kept integral: LDS address space)
             const int sb = (6 + 2 * (wn >> 1) + gb) * HALF_BYTES + boff;
@@ -1174,7 +1162,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[i][j], 0, 0, 0);
             Q_PHASE_SYNC_B();
-            if (fine && kt < 64) fine[kt * 8 + 0] = __builtin_amdgcn_s_memtime();
             // ---------------- phase 2: top-right
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -1189,7 +1176,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[i][2 + j], 0, 0, 0);
             Q_PHASE_SYNC_B();
-            if (fine && kt < 64) fine[kt * 8 + 1] = __builtin_amdgcn_s_memtime();
             // ---------------- phase 3: bottom-right
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1205,19 +1191,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b1[j][s], acc[4 + i][2 + j], 0, 0, 0);
             Q_PHASE_SYNC_B();
-            if (fine && kt < 64) fine[kt * 8 + 2] = __builtin_amdgcn_s_memtime();
             // ---------------- phase 4: bottom-left (no LDS reads); the K-tile's one counted wait: everything but A(kt+2) has landed
             if (a_issue) {
                 Q_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
                 Q_ADV_A();
-                if (fine && kt < 64) fine[kt * 8 + 4] = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (fine && kt < 64) fine[kt * 8 + 5] = __builtin_amdgcn_s_memtime();
             Q_PHASE_SYNC_A();
-            if (fine && kt < 64) fine[kt * 8 + 6] = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1225,7 +1207,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][s], b0[j][s], acc[4 + i][j], 0, 0, 0);
             Q_PHASE_SYNC_B();
-            if (fine && kt < 64) fine[kt * 8 + 3] = __builtin_amdgcn_s_memtime();
             ga = ga == 2 ? 0 : ga + 1;
             gb ^= 1;
         }
@@ -1366,14 +1347,11 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     const int nitems = ntile * sk.splits;
     // measured: persistence pays for the forward layout (+2..6 %); the whole-tile backward schedule is register-bound (no gain)
     const bool persist = pers_ok && fast && sched == 1 && d->layout == ECGVIT_GEMM_NT && !(sk.ablate & 3);
-    if ((sk.ablate & 4) && d->workspace && d->workspace_bytes >= (256 * 2 * 64 * 3 + 256 * 2 * 512) * 8 && d->layout == ECGVIT_GEMM_NT) sk.slabs = reinterpret_cast<float *>(d->workspace);
+    if ((sk.ablate & 4) && d->workspace && d->workspace_bytes >= 256 * 2 * 64 * 3 * 8 && d->layout == ECGVIT_GEMM_NT) sk.slabs = reinterpret_cast<float *>(d->workspace);
     else sk.ablate &= ~4;
     dim3 pgrid((unsigned)std::min(nitems, 256));
     static const bool q_ok = [] { const char *e = getenv("ECGVIT_GEMM_Q"); return !(e && e[0] == '0'); }();
     if (q_ok && sched_env < 0 && persist && d->K % 64 == 0 && d->K >= 192 && sk.splits == 1) {
-        // start stagger in cycles (k_per_split is unused by this kernel): a share of one tile period, only when blocks walk several tiles
-        static const int stag = [] { const char *e = getenv("ECGVIT_GEMM_STAGGER"); return e ? atoi(e) : 100; }();
-        sk.k_per_split = nitems >= 512 ? (int)(((int64_t)(d->K / BK) * 3000 + 8000) * stag / 100) : 0;
         if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_bf16_q_kernel<bf16_t>, pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems);
         else hipLaunchKernelGGL(gemm_bf16_q_kernel<float>, pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems);
         ECGVIT_CHECK_LAUNCH();

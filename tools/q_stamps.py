@@ -8,12 +8,11 @@ kin, nout = int(sys.argv[1]), int(sys.argv[2])
 M, bf = 512 * 251, torch.bfloat16
 X = torch.randn(M, kin, device='cuda').to(bf); W = (torch.randn(nout, kin, device='cuda') * 0.02).to(bf)
 Y = torch.empty(M, nout, device='cuda', dtype=bf)
-ws = torch.zeros(256 * 2 * 64 * 3 + 256 * 2 * 512, dtype=torch.int64, device='cuda')
+ws = torch.zeros(256 * 2 * 64 * 3, dtype=torch.int64, device='cuda')
 for _ in range(3):
     hip.gemm(hip.GEMM_NT, X, W, Y, M, nout, kin, kin, kin, nout, workspace=ws)
 torch.cuda.synchronize()
-t = ws.cpu()[:256 * 2 * 64 * 3].view(256, 2, 64, 3).double()
-fine = ws.cpu()[256 * 2 * 64 * 3:].view(256, 2, 64, 8).double()
+t = ws.cpu().view(256, 2, 64, 3).double()
 ntile = ((M + 255) // 256) * ((nout + 255) // 256)
 per = [ntile // 256 + (1 if b < ntile % 256 else 0) for b in range(256)]
 import numpy as np
@@ -30,15 +29,3 @@ for g in (0, 1):
 first = t[:, 0, 0, 0]
 print('block start spread (cycles):', float(first.max() - first.min()))
 
-# fine stamps of each block's 2nd tile: [end P1, end P2, end P3, end P4, before vmcnt, after vmcnt, after P4 first barrier+lgkm]
-nk = kin // 64
-for g in (0, 1):
-    f = fine[:, g, :nk]                                   # (256, nk, 8)
-    ok = f[:, 0, 0] > 0
-    f = f[ok]
-    p1 = f[:, 1:, 0] - f[:, :-1, 3]; p2 = f[:, :, 1] - f[:, :, 0]; p3 = f[:, :, 2] - f[:, :, 1]; p4 = f[:, :, 3] - f[:, :, 2]
-    wait = f[:, :, 5] - f[:, :, 4]; bar = f[:, :, 6] - f[:, :, 5]; pre = f[:, :, 4] - f[:, :, 2]; mf = f[:, :, 3] - f[:, :, 6]
-    print(f'group {g} ({int(ok.sum())} blocks): P1 {p1.mean():.0f}  P2 {p2.mean():.0f}  P3 {p3.mean():.0f}  P4 {p4.mean():.0f} '
-          f'[P4: dma-issue {pre.mean():.0f}, vmcnt wait {wait.mean():.0f} (p90 {np.percentile(wait.numpy(), 90):.0f}), barrier {bar.mean():.0f}, mfma+barrier {mf.mean():.0f}]')
-    print('   per-kt P4 vmcnt wait:', ' '.join(f'{v:.0f}' for v in wait.mean(0).tolist()[:16]))
-    print('   per-kt K-tile total :', ' '.join(f'{v:.0f}' for v in (f[:, 1:, 3] - f[:, :-1, 3]).mean(0).tolist()[:16]))
