@@ -93,7 +93,7 @@ def pmc_traffic(kernel_key, args):
     measured on this same command line; null when the run differs from the profiled workload."""
     if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512) or args.objective != 'supervised':
         return None
-    path = os.path.join(ROOT, 'profiles', 'r01_d_pmc_traffic_base_b512.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_traffic_base_b512.json')
     try:
         with open(path) as f:
             return json.load(f)[kernel_key]['hbm_bytes_per_launch']
@@ -264,10 +264,10 @@ def main():
             r = probe.result()
             if r:
                 out['roofline'] = {
-                    'kernel': 'gemm_bf16_pers_kernel<A_KC=true, B_KC=true, bf16 out, SCHED=1> (persistent 256x256x64 LDS-DMA GEMM of the '
-                              'Linear forward launches: QKV / attn-out / FFN-up / FFN-down)',
+                    'kernel': 'gemm_bf16_q_kernel<bf16 out> (persistent quadrant-phased 256x256x64 LDS-DMA GEMM, A . B^T: the Linear forward '
+                              'launches QKV / attn-out / FFN-up / FFN-down and, against the transposed weight shadows, their input-gradient launches)',
                     'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
-                    'traffic': pmc_traffic('gemm_nt', args), 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+                    'traffic': pmc_traffic('gemm_q', args), 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
                     'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
                 }
         if not args.no_cpu_baseline and world == 1:

@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pers_kernel(ecgvit_gemm_desc
 //     all of LDS, up to 96 KiB in flight per CU, ONE counted wait (vmcnt(4)) per K-tile, never a drain;
 //   * waves 4-7 run one barrier behind waves 0-3 (ping-pong on every SIMD) for the whole kernel, epilogues included: a
 //     wave drains its accumulators through a 4-KiB patch inside the A half-tile slot its OWN group just finished reading
-//     (group g reads only A-half g), so no extra barrier and no realignment bubble separates two output tiles.
+//     (group g reads only A-half g); the groups realign for the drain (one barrier each) so that both epilogues run concurrently.
 constexpr int HALF_BYTES = 16384;
 
 template <typename TO>
@@ -1015,15 +1015,24 @@ __device__ __forceinline__ void epilogue_store_q(f32x4 (&acc)[8][4], char *patch
     const int cq = lane & 7;
     const int n = n0 + wn * 64 + cq * 8;
     const int fr = lane & 15, fq = lane >> 4;
+    // per-lane patch offsets of the four accumulator registers of n-tile 0 (n-tile j adds 64 B: chunk += 4, swizzle bit untouched)
+    int woff[4];
 #pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * fq + r;
+        woff[r] = row * 256 + ((((fr >> 2) ^ (row & 1)) << 4) | ((fr & 3) << 2));
+    }
+    // The flag-dispatched row body below is large; it must exist ONCE in the instruction stream (I-cache), so the 16-row passes
+    // run as a rolled loop and only the accumulator -> patch copy, which needs static register indices, is selected by a switch.
+#pragma unroll 1
     for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * fq + r, col = 16 * j + fr;
-                *reinterpret_cast<float *>(patch + row * 256 + ((((col >> 2) ^ (row & 1)) << 4) | ((col & 3) << 2))) = acc[i][j][r];
-            }
+#define Q_COPY(I)                                                                                              \
+    case I:                                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int r = 0; r < 4; ++r)            \
+            *reinterpret_cast<float *>(patch + woff[r] + j * 64) = acc[I][j][r];                               \
+        break;
+        switch (i) { Q_COPY(0) Q_COPY(1) Q_COPY(2) Q_COPY(3) Q_COPY(4) Q_COPY(5) Q_COPY(6) default: Q_COPY(7) }
+#undef Q_COPY
 #pragma unroll 1
         for (int p = 0; p < 2; ++p) {
             const int rr = p * 8 + (lane >> 3);
@@ -1213,12 +1222,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
         // ---------------- output tile done: drain through the A half-tile slot this group just finished with
         const int next_it = it + (int)gridDim.x;
         const bool has_next = next_it < nitems;
-        if (!has_next && !late) __builtin_amdgcn_s_barrier();   // the trailing group's last barrier
+        // The two groups must drain TOGETHER (a staggered drain serialises them: each group's epilogue would run while the other
+        // waits at a barrier): the leading group waits here for the trailing group's last MFMA phase ...
+        if (!late) __builtin_amdgcn_s_barrier();
         const int gl = ga == 0 ? 2 : ga - 1;
         if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 1] = __builtin_amdgcn_s_memtime();
         epilogue_store_q<TO>(acc, smem + (3 * wm + gl) * HALF_BYTES + (wave & 3) * 4096, d, e, sk, cur.m0, cur.n0, wave, lane);
         if (stamps && lane == 0 && (wave & 3) == 0) stamps[(((int64_t)blockIdx.x * 2 + wm) * 64 + tile_no) * 3 + 2] = __builtin_amdgcn_s_memtime();
         tile_no = tile_no < 63 ? tile_no + 1 : 63;
+        // ... and the trailing group falls one barrier behind again (pairs with the leading group's first barrier of the next tile)
+        if (late && has_next) __builtin_amdgcn_s_barrier();
         if (!has_next) break;
         it = next_it;
         cur = nxt;

@@ -209,6 +209,53 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float *__restrict__ g, 
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) g[i] *= coef;
 }
 
+// ---- batched transpose of bf16 matrices that live at the SAME offsets in two flat buffers (shadow weights -> transposed shadows):
+//      table[4i..4i+3] = {element offset, rows, cols, index of the matrix's first 64x64 tile}; dst holds cols x rows row-major.
+//      One 64 x 64 tile per 256-thread block through LDS; 16-B accesses on both sides when the tile is interior.
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const bf16_t *__restrict__ src, bf16_t *__restrict__ dst,
+                                                                const int64_t *__restrict__ table, int nmat) {
+    __shared__ bf16_t tile[64][72];   // 144-B pitch: 16-B aligned rows, column reads spread over banks
+    int lo = 0, hi = nmat - 1;        // last matrix whose first tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[4 * mid + 3] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t off = table[4 * lo];
+    const int rows = (int)table[4 * lo + 1], cols = (int)table[4 * lo + 2];
+    const int t = (int)((int64_t)blockIdx.x - table[4 * lo + 3]);
+    const int tc = (cols + 63) / 64;
+    const int r0 = (t / tc) * 64, c0 = (t % tc) * 64;
+    const bf16_t *S = src + off;
+    bf16_t *D = dst + off;
+    const bool interior = r0 + 64 <= rows && c0 + 64 <= cols && (cols % 8) == 0 && (rows % 8) == 0 && (off % 8) == 0;
+    if (interior) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = p * 32 + (threadIdx.x >> 3), c = (threadIdx.x & 7) * 8;
+            *reinterpret_cast<bf16x8 *>(&tile[r][c]) = *reinterpret_cast<const bf16x8 *>(S + (int64_t)(r0 + r) * cols + c0 + c);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int c = p * 32 + (threadIdx.x >> 3), r = (threadIdx.x & 7) * 8;   // dst row = source column c, 8 source rows r..r+7
+            bf16x8 v;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tile[r + k][c];
+            *reinterpret_cast<bf16x8 *>(D + (int64_t)(c0 + c) * rows + r0 + r) = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int r = i >> 6, c = i & 63;
+            if (r0 + r < rows && c0 + c < cols) tile[r][c] = S[(int64_t)(r0 + r) * cols + c0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+            const int c = i >> 6, r = i & 63;
+            if (r0 + r < rows && c0 + c < cols) D[(int64_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float *__restrict__ s, bf16_t *__restrict__ d, int64_t count) {
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) d[i] = (bf16_t)s[i];
 }
@@ -298,6 +345,13 @@ int ecgvit_adamw_step(float *p, const float *g, float *m, float *v, void *p_lowp
 int ecgvit_clip_scale(float *g, int64_t count, const float *sumsq, float max_norm, float *norm_out, void *stream) {
     if (count <= 0 || !sumsq) return ECGVIT_EINVAL;
     hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_grid(count)), dim3(256), 0, as_stream(stream), g, count, sumsq, max_norm, norm_out);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_transpose_bf16_batched(const void *src, void *dst, const int64_t *table, int nmat, int64_t ntiles, void *stream) {
+    if (nmat <= 0 || ntiles <= 0 || ntiles > 0x7fffffff || !src || !dst || !table) return ECGVIT_EINVAL;
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)ntiles), dim3(256), 0, as_stream(stream), (const bf16_t *)src, (bf16_t *)dst, table, nmat);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

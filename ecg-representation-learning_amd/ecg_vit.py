@@ -246,7 +246,7 @@ class EcgVit(nn.Module):
         self._has_dropout = config.hidden_dropout_prob > 0 or config.attention_probs_dropout_prob > 0
         self._fwd_id = 0
         self._eng = None
-        self._pflat = self._gflat = self._wlow = None
+        self._pflat = self._gflat = self._wlow = self._wlow_t = self._tr_table = None
         self._wlow_version = -1
         self._own_names = [n for n, _ in self.named_parameters()]
         self._own_list = [p for _, p in self.named_parameters()]
@@ -298,7 +298,7 @@ class EcgVit(nn.Module):
                 p.data = v
         self._pflat = flat
         self._gflat = torch.zeros_like(flat)
-        self._wlow = None
+        self._wlow = self._wlow_t = self._tr_table = None
         self._eng = None
 
     def _apply(self, fn, *args, **kwargs):
@@ -325,10 +325,14 @@ class EcgVit(nn.Module):
                                   h=c.num_attention_heads, f=c.intermediate_size, Ly=c.num_hidden_layers, K=self.num_class,
                                   p_hidden=c.hidden_dropout_prob, p_emb=c.attention_probs_dropout_prob,
                                   dtype=self.compute_dtype, layout=self._layout)
+            self._wlow_t = self._tr_table = None
             if self.compute_dtype == torch.bfloat16:
                 self._wlow = torch.empty(self._layout.total, dtype=torch.bfloat16, device=self._pflat.device)
                 self._wlow_version = -1
-            self._eng.bind(self._pflat, self._gflat, self._wlow)
+                self._tr_table, self._tr_nmat, self._tr_tiles = self._eng.transposed_weight_table(self._pflat.device)
+                if self._tr_table is not None:
+                    self._wlow_t = torch.zeros(self._layout.total, dtype=torch.bfloat16, device=self._pflat.device)
+            self._eng.bind(self._pflat, self._gflat, self._wlow, self._wlow_t)
             self._eng.input_transform = getattr(self, '_input_transform', None)
         if self.compute_dtype == torch.bfloat16:
             self.refresh_low_precision_weights()
@@ -341,7 +345,14 @@ class EcgVit(nn.Module):
         if force or ver != self._wlow_version:
             hip.check(hip.lib().ecgvit_cast_f32_to_bf16(self._pflat.data_ptr(), self._wlow.data_ptr(), self._layout.total,
                                                         hip.stream()), 'cast_f32_to_bf16')
+            self.refresh_transposed_weights()
             self._wlow_version = ver
+
+    def refresh_transposed_weights(self):
+        """W^T shadows of the block Linears (input-gradient GEMMs then run on the forward kernel); call after `_wlow` changed"""
+        if getattr(self, '_wlow_t', None) is not None:
+            hip.check(hip.lib().ecgvit_transpose_bf16_batched(self._wlow.data_ptr(), self._wlow_t.data_ptr(), self._tr_table.data_ptr(),
+                                                              self._tr_nmat, self._tr_tiles, hip.stream()), 'transpose_bf16_batched')
 
     def set_input_transform(self, transform):
         """f2: give the model RAW records; Normalize / TimeEndPad / TimeOut run fused inside the patch-embed load

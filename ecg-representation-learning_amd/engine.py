@@ -10,6 +10,8 @@ stream.  What each launch replaces in the reference is cited at the call site
 import math
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import hip
@@ -21,6 +23,9 @@ LN_EPS = 1e-5  # nn.LayerNorm default, used by vit_pytorch PreNorm / mlp_head
 
 def _align(n, a=8):
     return (n + a - 1) // a * a
+
+
+_DGRAD_T = os.environ.get('ECGVIT_DGRAD_T', '1') != '0'   # experiments: 0 = input gradients on the A.B kernel
 
 
 class ParamLayout:
@@ -102,17 +107,53 @@ class VitEngine:
         self.on_grads_ready = None   # callback(tag): a gradient bucket ('head' | 'layer{i}' | 'embed' | 'pretrain') is final
 
     # ---------------------------------------------------------------- buffers
-    def bind(self, pflat, gflat, wlow=None):
-        """pflat/gflat: flat f32 params / grads. wlow: flat bf16 shadow of pflat (bf16 engine only)."""
+    def bind(self, pflat, gflat, wlow=None, wlow_t=None):
+        """pflat/gflat: flat f32 params / grads. wlow: flat bf16 shadow of pflat (bf16 engine only); wlow_t: same layout, the trunk's
+        Linear weights stored TRANSPOSED (see `transposed_weight_table`), so their input-gradient products run as A . B^T."""
         lay = self.layout
         self.P32 = {k: lay.view(pflat, k) for k in lay.entries}
         self.G32 = {k: lay.view(gflat, k) for k in lay.entries}
+        self.WT = {}
         if self.dtype == torch.bfloat16:
             assert wlow is not None and wlow.dtype == torch.bfloat16
             self.W = {k: lay.view(wlow, k) for k in lay.entries}
+            if wlow_t is not None:
+                for k in self.transposed_weight_names():
+                    off, shape = lay.entries[k][0], lay.entries[k][1]
+                    self.WT[k] = wlow_t[off:off + shape[0] * shape[1]].view(shape[1], shape[0])
         else:
             self.W = self.P32
         self.device = pflat.device
+
+    def transposed_weight_names(self):
+        """Linear weights of the transformer blocks whose dgrad is large enough for the 256^2 forward kernel (K % 64 == 0, N >= 256)"""
+        out = []
+        for i in range(self.Ly):
+            lp = f'vit.transformer.layers.{i}.'
+            for k in ('0.fn.to_qkv.weight', '0.fn.to_out.0.weight', '1.fn.net.0.weight', '1.fn.net.3.weight'):
+                rows, cols = self.layout.entries[lp + k][1]
+                if rows % 64 == 0 and rows >= 192 and cols >= 256 and cols % 8 == 0:
+                    out.append(lp + k)
+        return out
+
+    def transposed_weight_table(self, device):
+        """(table tensor int64 [nmat, 4] on `device`, nmat, ntiles) for ecgvit_transpose_bf16_batched"""
+        rows_, t = [], 0
+        for k in self.transposed_weight_names():
+            off, (r, c) = self.layout.entries[k][0], self.layout.entries[k][1]
+            rows_.append([off, r, c, t])
+            t += ((r + 63) // 64) * ((c + 63) // 64)
+        if not rows_:
+            return None, 0, 0
+        return torch.tensor(rows_, dtype=torch.int64, device=device), len(rows_), t
+
+    def _dgrad(self, dY, name, dX, M, kin, nout, **kw):
+        """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one"""
+        wt = self.WT.get(name)
+        if wt is not None and M >= 2048 and _DGRAD_T:
+            hip.gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
+        else:
+            hip.gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
 
     def _alloc(self, B, masked=False, m=0):
         key = (B, masked, m)
@@ -424,10 +465,10 @@ class VitEngine:
             self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M)
             # dgrad with GELU' (+ dropout mask) epilogue; the epilogue also reduces the columns = gradient of the FFN-up bias
             epi = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0)
-            hip.gemm(GEMM_NN, dY, W[lp + '1.fn.net.3.weight'], a['dh'], M, f, d, d, f, f, epilogue=epi, aux=L['hpre'], ldaux=f,
-                     dropout_p=ph, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
+            self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, epilogue=epi, aux=L['hpre'], ldaux=f,
+                        dropout_p=ph, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
-            hip.gemm(GEMM_NN, a['dh'], W[lp + '1.fn.net.0.weight'], a['dxn'], M, d, f, f, d, d)
+            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f)
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
             self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
                                G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2)
@@ -435,14 +476,14 @@ class VitEngine:
             dY = a['dxm'] if ph > 0 else dX
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
-            hip.gemm(GEMM_NN, dY, W[lp + '0.fn.to_out.0.weight'], a['dattn'], M, d, d, d, d, d)
+            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
                                              dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
             else:
                 self._attn_bwd_f32(L, B, ph, s0 + 1)
             self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M)
-            hip.gemm(GEMM_NN, a['dqkv'], W[lp + '0.fn.to_qkv.weight'], a['dxn'], M, d, 3 * d, 3 * d, d, d)
+            self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d)
             if i > 0:
                 # LN1 backward; its output feeds layer i-1's FFN-down site (mask seed of layer i-1, bias net.3.bias)
                 lq = f'{pre}transformer.layers.{i - 1}.'

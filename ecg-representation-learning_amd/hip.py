@@ -71,6 +71,7 @@ SIGNATURES = {
     'ecgvit_clip_scale': (c_int, [_P, _L, _P, _F, _P, _P]),
     'ecgvit_cast_f32_to_bf16': (c_int, [_P, _P, _L, _P]),
     'ecgvit_cast_bf16_to_f32': (c_int, [_P, _P, _L, _P]),
+    'ecgvit_transpose_bf16_batched': (c_int, [_P, _P, _P, _I, _L, _P]),
     'ecgvit_mask_embed_finish': (c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'ecgvit_mask_embed_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'ecgvit_gather_rows': (c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),

@@ -179,6 +179,7 @@ class HipTrainStep:
             model._wlow.data_ptr() if model._wlow is not None else None, gflat.numel(), self.sumsq.data_ptr(),
             1.0 / self.world, self.max_grad_norm, lr, 0.9, 0.999, 1e-8, self.wd, self.step_count, 1 if self.decoupled else 0,
             self.norm_out.data_ptr(), st), 'adamw_step')
+        model.refresh_transposed_weights()   # the optimiser kernel rewrote the bf16 shadows
         # non-blocking readback of (norm, finite flag) into pinned host memory; inspected when its event has completed
         self.norm_host.copy_(self.norm_out, non_blocking=True)
         self._flag_event.record()

@@ -194,6 +194,11 @@ int ecgvit_adamw_step(float *p, const float *g, float *m, float *v, void *p_lowp
 int ecgvit_clip_scale(float *g, int64_t count, const float *sumsq, float max_norm, float *norm_out, void *stream);
 int ecgvit_cast_f32_to_bf16(const float *src, void *dst, int64_t count, void *stream);
 int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *stream);
+/* Transposed bf16 shadows of the Linear weights: with W^T at hand the input-gradient product dX = dY . W (nn.Linear backward) runs
+ * on the forward (A . B^T) kernel.  src / dst: flat bf16 buffers with identical layouts; table (DEVICE, int64 [nmat][4]) =
+ * {element offset, rows, cols, index of the matrix's first 64x64 tile}; dst + offset receives the cols x rows transpose.
+ * ntiles = total number of 64x64 tiles over all matrices. */
+int ecgvit_transpose_bf16_batched(const void *src, void *dst, const int64_t *table, int nmat, int64_t ntiles, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * masked pre-train objective (build's own definition; absent from the reference)

@@ -501,3 +501,28 @@ def test_load_trained_reference_checkpoint_and_attention_export(tmp_path):
     assert amap.shape == (L, conf.max_signal_length // conf.patch_size)
     assert max_err(amap, res) < 1e-5 and float(amap.max()) == 1.0
     assert max_err(logits, o32.logits[0]) < 1e-5
+
+
+def test_bf16_input_gradients_via_transposed_shadows_match_plain_path():
+    """dgrad on the forward kernel against W^T shadows vs the A.B path on W: same bf16 products, f32 accumulation in another order"""
+    kw = dict(max_signal_length=5000, patch_size=20, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024)
+    conf, ref, m, x, y = _oracle_pair(kw, 16, BF16)                      # M = 16 * 251 = 4016 rows >= 2048: the large-shape kernels
+    m.train()
+    eng = m._engine()
+    assert len(eng.WT) == 8 and eng.WT['vit.transformer.layers.0.1.fn.net.0.weight'].shape == (256, 1024)
+    torch.testing.assert_close(eng.WT['vit.transformer.layers.1.0.fn.to_qkv.weight'].float().t(),
+                               eng.W['vit.transformer.layers.1.0.fn.to_qkv.weight'].float(), rtol=0, atol=0)
+    m(sample_values=x.cuda(), labels=y.cuda()).loss.backward()
+    g_t = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad(set_to_none=True)
+    saved, eng.WT = eng.WT, {}
+    m(sample_values=x.cuda(), labels=y.cuda()).loss.backward()
+    eng.WT = saved
+    for k, p in m.named_parameters():
+        assert rel_err(g_t[k], p.grad) < 3e-3, (k, rel_err(g_t[k], p.grad))
+    # and after a fused optimiser step the transposed shadows follow the updated weights
+    ts = E.HipTrainStep(m, dict(n_step=20), sync_nonfinite=True)
+    ts.step(x.cuda(), y.cuda())
+    ts.finish()
+    for k, wt in eng.WT.items():
+        assert torch.equal(wt.t(), eng.W[k]) and torch.equal(eng.W[k], eng.P32[k].to(BF16)), k

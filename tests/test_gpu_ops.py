@@ -615,3 +615,23 @@ def test_eval_counts_eval_set_size_rank_identity():
     np.testing.assert_array_equal(c2[:4 + K], cnt[:4 + K])
     # in-kernel f32 sigmoid vs torch's: tie structure of saturated values may differ by a few pairs at most
     assert np.max(np.abs(c2[4 + K:] - cnt[4 + K:]) / np.maximum(cnt[4 + K:], 1)) < 1e-5
+
+
+def test_transpose_bf16_batched():
+    """transposed shadow weights: several matrices at their offsets in one flat buffer, interior and ragged tiles, untouched gaps"""
+    g = torch.Generator().manual_seed(4)
+    shapes = [(768, 2304), (64, 64), (200, 72), (3072, 768), (8, 8)]
+    offs, table, t, total = [], [], 0, 16
+    for r, c in shapes:
+        offs.append(total)
+        table.append([total, r, c, t])
+        t += ((r + 63) // 64) * ((c + 63) // 64)
+        total += r * c + 24                                           # gaps (other parameters) must stay untouched
+    src = torch.randn(total, generator=g).to(BF16).cuda()
+    dst = torch.full((total,), 7.0, dtype=BF16, device='cuda')
+    tb = torch.tensor(table, dtype=torch.int64, device='cuda')
+    check(lib().ecgvit_transpose_bf16_batched(ptr(src), ptr(dst), ptr(tb), len(shapes), t, stream()), 'transpose')
+    expect = torch.full((total,), 7.0, dtype=BF16)
+    for (r, c), o in zip(shapes, offs):
+        expect[o:o + r * c] = src[o:o + r * c].cpu().view(r, c).t().contiguous().view(-1)
+    assert torch.equal(dst.cpu(), expect)

@@ -17,6 +17,7 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 E = hip
+W2t = W2.t().contiguous()
 cases = {
  'up plain': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f),
  'up bias': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f, epilogue=E.EPI_BIAS, bias=bias),
@@ -26,6 +27,8 @@ cases = {
  'dgrad gelu_bwd': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f, epilogue=E.EPI_GELU_BWD, aux=PRE, ldaux=f),
  'dgrad gelu_bwd+drop': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f, epilogue=E.EPI_GELU_BWD | E.EPI_DROPOUT, aux=PRE, ldaux=f, dropout_p=0.1, seed=5),
  'dgrad gelu_bwd+drop+colsum': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f, epilogue=E.EPI_GELU_BWD | E.EPI_DROPOUT | E.EPI_COLSUM, aux=PRE, ldaux=f, dropout_p=0.1, seed=5, workspace=ws, colsum_out=cs),
+ 'dgradT plain': lambda: hip.gemm(E.GEMM_NT, dY, W2t, H, M, f, d, d, d, f),
+ 'dgradT gelu_bwd+drop+colsum': lambda: hip.gemm(E.GEMM_NT, dY, W2t, H, M, f, d, d, d, f, epilogue=E.EPI_GELU_BWD | E.EPI_DROPOUT | E.EPI_COLSUM, aux=PRE, ldaux=f, dropout_p=0.1, seed=5, workspace=ws, colsum_out=cs),
  'down plain': lambda: hip.gemm(E.GEMM_NT, H, W2, Y, M, d, f, f, f, d),
  'down bias+res+drop': lambda: hip.gemm(E.GEMM_NT, H, W2, Y, M, d, f, f, f, d, epilogue=E.EPI_BIAS | E.EPI_RESIDUAL | E.EPI_DROPOUT, bias=bd, residual=R, ldr=d, dropout_p=0.1, seed=7),
 }

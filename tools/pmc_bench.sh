@@ -13,7 +13,8 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob('$O/*/*/*counter_collection.csv')):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'gemm_bf16_pers_kernel<true, true' in n: k = 'gemm_nt'          # the dominant symbol: persistent forward GEMM
+        if 'gemm_bf16_q_kernel' in n: k = 'gemm_q'                          # the dominant symbol: persistent A.B^T GEMM (forward + dgrad)
+        elif 'gemm_bf16_pers_kernel<true, true' in n: k = 'gemm_nt'
         elif 'gemm_bf16_v2_kernel<true, true' in n: k = 'gemm_nt_patch'     # patch-embed (K = 240: generic DMA path)
         elif 'gemm_bf16_v2_kernel<true, false' in n: k = 'gemm_nn'
         elif 'gemm_bf16_v2_kernel<false, false' in n: k = 'gemm_tn'
