@@ -119,6 +119,15 @@ __device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint
         v[2 * k + 1] *= (h >> 16) >= thresh ? inv_keep : 0.f;
     }
 }
+// the 8 multipliers themselves (for epilogues that fold the mask into a saved tensor)
+__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t h = pair_hash(seed, idx0 + 2 * k);
+        m[2 * k] = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+        m[2 * k + 1] = (h >> 16) >= thresh ? inv_keep : 0.f;
+    }
+}
 static inline uint32_t dropout_threshold(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 65536.0 + 0.5;
@@ -130,7 +139,7 @@ static inline uint32_t dropout_threshold(float p) {
 //      GELU' reuses the same exponential (erf(x/sqrt2) is built on e^{-x^2/2} = sqrt(2 pi) * pdf) -----------------
 __device__ __forceinline__ void gelu_fast_parts(float x, float &cdf, float &pdf) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
     const float ex = __expf(-z * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * ex;
@@ -138,6 +147,7 @@ __device__ __forceinline__ void gelu_fast_parts(float x, float &cdf, float &pdf)
     pdf = 0.39894228040143267794f * ex;
 }
 __device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }
+__device__ __forceinline__ void gelu_fast_both(float x, float &y, float &dy) { float c, p; gelu_fast_parts(x, c, p); y = x * c; dy = fmaf(x, p, c); }
 __device__ __forceinline__ float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return c + x * p; }
 
 // ---- epilogue parameters shared by the f32 and bf16 GEMMs -------------------------------------
@@ -159,13 +169,20 @@ struct EpiParams {
 template <typename TO> __device__ __forceinline__ float epilogue_value(float acc, int64_t m, int n, const EpiParams &e) {
     float v = acc * e.alpha;
     if (e.flags & ECGVIT_EPI_BIAS) v += e.bias[n];
+    const float mult = (e.flags & ECGVIT_EPI_DROPOUT) ? dropout_mult(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep) : 1.f;
     if (e.flags & ECGVIT_EPI_GELU) {
-        reinterpret_cast<TO *>(e.aux)[m * e.ldaux + n] = from_f32<TO>(v);
-        // GELU of the value as STORED (so backward, which re-reads aux, sees the same pre-activation)
-        v = gelu_erf(to_f32<TO>(from_f32<TO>(v)));
+        if (e.flags & ECGVIT_EPI_GELU_GRAD_AUX) {
+            reinterpret_cast<TO *>(e.aux)[m * e.ldaux + n] = from_f32<TO>(gelu_erf_grad(v) * mult);
+            v = gelu_erf(v);
+        } else {
+            reinterpret_cast<TO *>(e.aux)[m * e.ldaux + n] = from_f32<TO>(v);
+            // GELU of the value as STORED (so backward, which re-reads aux, sees the same pre-activation)
+            v = gelu_erf(to_f32<TO>(from_f32<TO>(v)));
+        }
     }
-    if (e.flags & ECGVIT_EPI_DROPOUT) v *= dropout_mult(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep);
+    v *= mult;
     if (e.flags & ECGVIT_EPI_GELU_BWD) v *= gelu_erf_grad(to_f32<TO>(reinterpret_cast<const TO *>(e.aux)[m * e.ldaux + n]));
+    if (e.flags & ECGVIT_EPI_MUL_AUX) v *= to_f32<TO>(reinterpret_cast<const TO *>(e.aux)[m * e.ldaux + n]);
     if (e.flags & ECGVIT_EPI_RESIDUAL) v += to_f32<TO>(reinterpret_cast<const TO *>(e.residual)[m * e.ldr + n]);
     return v;
 }

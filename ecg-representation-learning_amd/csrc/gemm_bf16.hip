@@ -203,19 +203,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(ecgvit_gemm_desc d, E
             for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
         }
         if constexpr (sizeof(TO) == 2) {
+            float mult[8];
+            const bool drop = e.flags & ECGVIT_EPI_DROPOUT;
+            if (drop) dropout_mask8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, mult);
             if (e.flags & ECGVIT_EPI_GELU) {
-                Vec16<bf16_t> pre;
+                Vec16<bf16_t> sav;
+                if (e.flags & ECGVIT_EPI_GELU_GRAD_AUX) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
-                st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
+                    for (int k = 0; k < 8; ++k) {
+                        float dy;
+                        gelu_fast_both(v[k], v[k], dy);
+                        sav.set(k, drop ? dy * mult[k] : dy);
+                    }
+                } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
+                    for (int k = 0; k < 8; ++k) sav.set(k, v[k]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = gelu_fast(sav.get(k));
+                }
+                st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, sav);
             }
-            if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
+            if (drop) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= mult[k];
+            }
             if (e.flags & ECGVIT_EPI_GELU_BWD) {
                 const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
+            }
+            if (e.flags & ECGVIT_EPI_MUL_AUX) {
+                const Vec16<bf16_t> a = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] *= a.get(k);
             }
             if (e.flags & ECGVIT_EPI_RESIDUAL) {
                 const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);
@@ -308,10 +328,10 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((a_kc || b_kc) && d->K % 8 != 0) return ECGVIT_EINVAL;      // K-contiguous operands move 8-element chunks
     if (!a_kc && d->M % 8 != 0) return ECGVIT_EINVAL;
     if (d->out_dtype == ECGVIT_F32 &&
-        (d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_RESIDUAL | ECGVIT_EPI_DROPOUT)))
+        (d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_RESIDUAL | ECGVIT_EPI_DROPOUT)))
         return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_BIAS) && (reinterpret_cast<uintptr_t>(d->bias) % 16)) return ECGVIT_EINVAL;
-    if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
+    if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
     if (use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_v2_launch(d, s);

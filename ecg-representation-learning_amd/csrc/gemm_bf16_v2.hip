@@ -147,19 +147,39 @@ __device__ __forceinline__ void epi_row8(const f32x4 c0, const f32x4 c1, int64_t
         for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
     }
     if constexpr (sizeof(TO) == 2) {
+        float mult[8];
+        const bool drop = e.flags & ECGVIT_EPI_DROPOUT;
+        if (drop) dropout_mask8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, mult);
         if (e.flags & ECGVIT_EPI_GELU) {
-            Vec16<bf16_t> pre;
+            Vec16<bf16_t> sav;
+            if (e.flags & ECGVIT_EPI_GELU_GRAD_AUX) {   // aux = gelu'(v) * dropout multiplier: all the backward of this site needs
 #pragma unroll
-            for (int k = 0; k < 8; ++k) pre.set(k, v[k]);
-            st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, pre);
+                for (int k = 0; k < 8; ++k) {
+                    float dy;
+                    gelu_fast_both(v[k], v[k], dy);
+                    sav.set(k, drop ? dy * mult[k] : dy);
+                }
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = gelu_fast(pre.get(k));
+                for (int k = 0; k < 8; ++k) sav.set(k, v[k]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = gelu_fast(sav.get(k));
+            }
+            st16(reinterpret_cast<bf16_t *>(e.aux) + m * e.ldaux + n, sav);
         }
-        if (e.flags & ECGVIT_EPI_DROPOUT) dropout_mult8(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep, v);
+        if (drop) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= mult[k];
+        }
         if (e.flags & ECGVIT_EPI_GELU_BWD) {
             const Vec16<bf16_t> pre = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] *= gelu_fast_grad(pre.get(k));
+        }
+        if (e.flags & ECGVIT_EPI_MUL_AUX) {
+            const Vec16<bf16_t> a = ld16(reinterpret_cast<const bf16_t *>(e.aux) + m * e.ldaux + n);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= a.get(k);
         }
         if (e.flags & ECGVIT_EPI_RESIDUAL) {
             const Vec16<bf16_t> res = ld16(reinterpret_cast<const bf16_t *>(e.residual) + m * e.ldr + n);

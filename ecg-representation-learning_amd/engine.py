@@ -16,7 +16,7 @@ import torch
 
 from . import hip
 from .hip import lib, check, ptr, stream, GEMM_NT, GEMM_NN, GEMM_TN
-from .hip import EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM
+from .hip import EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM, EPI_GELU_GRAD_AUX, EPI_MUL_AUX
 
 LN_EPS = 1e-5  # nn.LayerNorm default, used by vit_pytorch PreNorm / mlp_head
 
@@ -265,7 +265,9 @@ class VitEngine:
                      bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
             # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
             self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M)
-            epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0)
+            # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
+            # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
+            epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
             hip.gemm(GEMM_NT, L['xn2'], W[lp + '1.fn.net.0.weight'], L['hact'], M, f, d, d, d, f, epilogue=epi,
                      bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
@@ -464,9 +466,12 @@ class VitEngine:
                 self._colsum(dY, d, G[lp + '1.fn.net.3.bias'], M, d)
             self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M)
             # dgrad with GELU' (+ dropout mask) epilogue; the epilogue also reduces the columns = gradient of the FFN-up bias
-            epi = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0)
+            if self.dtype == torch.bfloat16:
+                epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
+            else:
+                epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
             self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, epilogue=epi, aux=L['hpre'], ldaux=f,
-                        dropout_p=ph, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
+                        dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
             self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f)
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)

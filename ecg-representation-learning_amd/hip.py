@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
+EPI_GELU_GRAD_AUX, EPI_MUL_AUX = 128, 256
 
 _ERR = {1: 'ECGVIT_EINVAL (unsupported shape / argument)', 2: 'ECGVIT_ELAUNCH (HIP launch failure)'}
 

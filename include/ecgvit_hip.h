@@ -57,6 +57,10 @@ int ecgvit_abi_version(void);
 #define ECGVIT_EPI_ACCUM 16     /* v += C[m,n]   (read-modify-write of the output)                   */
 #define ECGVIT_EPI_DROPOUT 32   /* v = keep(seed, m*N+n) ? v / (1-p) : 0 ; applied after GELU / GELU_BWD,
                                    before RESIDUAL (the mask is a pure function of (seed, element))   */
+#define ECGVIT_EPI_GELU_GRAD_AUX 128 /* modifies EPI_GELU: aux[m,n] = gelu_erf'(v) * (the EPI_DROPOUT multiplier of this element, if any)
+                                   instead of v -- everything the backward of `dropout(gelu(.))` needs, so that the input-gradient GEMM
+                                   of the next Linear finishes with EPI_MUL_AUX alone (no erf, no mask hash in the backward)    */
+#define ECGVIT_EPI_MUL_AUX 256  /* v *= aux[m,n]                                                                              */
 #define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
                                    the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
                                    max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */

@@ -635,3 +635,34 @@ def test_transpose_bf16_batched():
     for (r, c), o in zip(shapes, offs):
         expect[o:o + r * c] = src[o:o + r * c].cpu().view(r, c).t().contiguous().view(-1)
     assert torch.equal(dst.cpu(), expect)
+
+
+@pytest.mark.parametrize('shape', [(260, 136, 128), (4100, 520, 256)])    # 128^2 kernel / persistent 256^2 kernel
+def test_gemm_bf16_saved_gelu_grad_and_mul_aux(shape):
+    """EPI_GELU_GRAD_AUX: C = [dropout](gelu(pre)), aux = gelu'(pre) * dropout multiplier; EPI_MUL_AUX: C = acc * aux.
+    Together they are forward and backward of `dropout(gelu(Linear))` with the mask hashed once."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M)
+    A, B = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    bias = torch.randn(N, generator=g)
+    pre = _gemm_ref(hip.GEMM_NT, A.float(), B.float()) + bias.double()
+    C = torch.zeros(M, N, device='cuda', dtype=BF16)
+    aux = torch.zeros(M, N, device='cuda', dtype=BF16)
+    Ad, Bd, bd = dev(A), dev(B), dev(bias)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX, bias=bd, aux=aux, ldaux=N)
+    assert rel_err(C, gelu(pre)) < 4e-3 and rel_err(aux, gelu_grad(pre)) < 4e-3
+    # with dropout: the kept set of C and aux is the same, both scaled by 1/(1-p); identical to the plain-dropout epilogue's mask
+    p = 0.25
+    C2, aux2, C3 = torch.zeros_like(C), torch.zeros_like(aux), torch.zeros_like(C)
+    kw = dict(bias=bd, dropout_p=p, seed=99)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C2, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX | hip.EPI_DROPOUT, aux=aux2, ldaux=N, **kw)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C3, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_DROPOUT, **kw)
+    keep = (C3 != 0).cpu()
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+    assert rel_err(C2, gelu(pre) * keep / (1 - p)) < 4e-3
+    assert rel_err(aux2, gelu_grad(pre) * keep / (1 - p)) < 4e-3
+    # backward multiply
+    dY, W = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    D = torch.zeros(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, dev(dY), dev(W), D, M, N, K, K, K, N, epilogue=hip.EPI_MUL_AUX, aux=aux2, ldaux=N)
+    assert rel_err(D, _gemm_ref(hip.GEMM_NT, dY.float(), W.float()) * aux2.float().double().cpu()) < 4e-3
