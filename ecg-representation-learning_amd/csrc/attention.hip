@@ -197,13 +197,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
             if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
+                const uint32_t hb = pair_base(seed, rowidx + (uint32_t)(kt * 32 + 4 * lh));   // one Weyl multiply per 32-key tile
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // even
-                    float m0, m1;
-                    dropout_pair(seed, rowidx + key, thresh, inv_keep, m0, m1);
-                    s[r] *= m0;
-                    s[r + 1] *= m1;
+                    // keys (r&3) + 8*(r>>2) + 4*lh, pairs (r, r+1): pair offset ((r&3)>>1) + 4*(r>>2) from the tile's first pair
+                    const uint32_t hh = pair_finish(hb + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * ECGVIT_WEYL);
+                    s[r] *= (hh & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+                    s[r + 1] *= (hh >> 16) >= thresh ? inv_keep : 0.f;
                 }
             }
 #pragma unroll
@@ -322,8 +322,12 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 
     for (int qb = (ablate & 4) ? nqb : 0; qb < nqb; ++qb) {
         const char *Qrow = Qimg + qb * 4096, *dOrow = dOimg + qb * 4096;
-        const uint32_t NPu = (uint32_t)((N + 1) & ~1);
-        const uint32_t drop_base = ((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * NPu + (uint32_t)mykey;   // row q = qb*32
+        // dropout: element index = ((bh*N + q) * NP + key), NP = N rounded up to even (the forward kernel's function); keys (2j, 2j+1)
+        // of one query share a hash and sit on adjacent lanes, so each lane finishes the hashes of TWO of its four queries per group
+        // and takes the other two from its neighbour (DPP quad_perm swap): 2 hashes per 4 elements instead of 4
+        const uint32_t hstep = (uint32_t)((N + 1) >> 1) * ECGVIT_WEYL;   // one query down = NP/2 pairs
+        const uint32_t hq0 = seed_mix(seed) + (((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)(mykey >> 1)) * ECGVIT_WEYL;
+        const uint32_t podd = (uint32_t)(lane & 1);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -337,14 +341,22 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_s[qb * 32 + 8 * g4 + 4 * lh]);
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_s[qb * 32 + 8 * g4 + 4 * lh]);
+            uint32_t hk[4];
+            if constexpr (DROP) {
+                const uint32_t hg = hq0 + (uint32_t)(8 * g4 + 4 * lh) * hstep + (podd * 2u) * hstep;   // my two queries: k = 2*podd, 2*podd + 1
+                const uint32_t mine0 = pair_finish(hg), mine1 = pair_finish(hg + hstep);
+                const uint32_t oth0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                const uint32_t oth1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xB1, 0xF, 0xF, true);
+                hk[0] = podd ? oth0 : mine0; hk[1] = podd ? oth1 : mine1;
+                hk[2] = podd ? mine0 : oth0; hk[3] = podd ? mine1 : oth1;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int r = 4 * g4 + k;
                 float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
                 float g = dp[r];
                 if constexpr (DROP) {
-                    // element index = ((bh*N + q) * NP + key), NP = N rounded up to even (same function as the forward kernel)
-                    const float mlt = dropout_mult(seed, drop_base + (uint32_t)(8 * g4 + 4 * lh + k) * NPu, thresh, inv_keep);
+                    const float mlt = ((hk[k] >> (podd * 16u)) & 0xFFFFu) >= thresh ? inv_keep : 0.f;
                     g *= mlt;
                     s[r] = p * mlt;  // dropped probabilities feed dV
                 } else {

@@ -87,17 +87,21 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
-// ---- counter-based dropout mask: keep(seed, element) is a pure function, recomputed in backward ----
-// One 32-bit murmur-style hash per PAIR of consecutive elements, 16 random bits each (threshold = p * 2^16):
-// ~4 VALU ops per element instead of the ~40 of a 64-bit mixer (the FFN epilogues touch 4e8 elements per launch).
-// The element index is a 32-BIT WRAPPING counter (callers may pass wider integers; only the low 32 bits count): masks of
-// tensors beyond 2^32 elements repeat, which is harmless for dropout, and every index computation stays 32-bit VALU.
-__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint32_t idx) {
-    // counter + (seed * golden ratio), then the 2-multiply "lowbias32" finaliser
-    uint32_t h = (idx >> 1) + (uint32_t)seed * 0x9E3779B1u;
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+// ---- counter-based dropout mask: keep(seed, element) is a pure function, recomputed wherever it is needed ----
+// One 32-bit hash per PAIR of consecutive elements (2j, 2j+1), 16 random bits each (threshold = p * 2^16).  The pair counter goes
+// through a Weyl step (counter * golden ratio + seed mix) and ONE xorshift-multiply-xorshift round: consecutive pairs cost one add
+// for the Weyl step (the multiply is shared by a run of pairs) and 8 more ALU slots (v_mul_lo_u32 is quarter rate) -- the FFN
+// epilogues and the attention kernels evaluate 4e8 masks per launch, so the hash is priced per instruction.
+// The element index is a 32-BIT WRAPPING counter (callers may pass wider integers; only the low 32 bits count): masks of tensors
+// beyond 2^32 elements repeat, which is harmless for dropout, and every index computation stays 32-bit VALU.
+#define ECGVIT_WEYL 0x9E3779B1u
+__device__ __forceinline__ uint32_t seed_mix(uint64_t seed) { return (uint32_t)seed * 0x85EBCA6Bu + (uint32_t)(seed >> 32) * 0xC2B2AE35u + 0x27D4EB2Fu; }
+__device__ __forceinline__ uint32_t pair_base(uint64_t seed, uint32_t idx) { return (idx >> 1) * ECGVIT_WEYL + seed_mix(seed); }
+__device__ __forceinline__ uint32_t pair_finish(uint32_t h) {
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 16;
     return h;
 }
+__device__ __forceinline__ uint32_t pair_hash(uint64_t seed, uint32_t idx) { return pair_finish(pair_base(seed, idx)); }
 // both elements of the pair starting at EVEN index idx0
 __device__ __forceinline__ void dropout_pair(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float &m0, float &m1) {
     const uint32_t h = pair_hash(seed, idx0);
@@ -110,23 +114,25 @@ __device__ __forceinline__ float dropout_mult(uint64_t seed, uint32_t idx, uint3
     const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
     return r >= thresh ? inv_keep : 0.f;
 }
-// 8 consecutive elements starting at an EVEN index: 4 hashes
-__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
+// multipliers of VN (4 or 8) consecutive elements starting at an EVEN index: one Weyl multiply, VN/2 finishers
+template <int VN> __device__ __forceinline__ void dropout_maskN(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[VN]) {
+    const uint32_t base = pair_base(seed, idx0);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t h = pair_hash(seed, idx0 + 2 * k);
-        v[2 * k] *= (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
-        v[2 * k + 1] *= (h >> 16) >= thresh ? inv_keep : 0.f;
-    }
-}
-// the 8 multipliers themselves (for epilogues that fold the mask into a saved tensor)
-__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[8]) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t h = pair_hash(seed, idx0 + 2 * k);
+    for (int k = 0; k < VN / 2; ++k) {
+        const uint32_t h = pair_finish(base + (uint32_t)k * ECGVIT_WEYL);
         m[2 * k] = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
         m[2 * k + 1] = (h >> 16) >= thresh ? inv_keep : 0.f;
     }
+}
+__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[8]) {
+    dropout_maskN<8>(seed, idx0, thresh, inv_keep, m);
+}
+// 8 consecutive values starting at an EVEN index, multiplied in place
+__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
+    float m[8];
+    dropout_maskN<8>(seed, idx0, thresh, inv_keep, m);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= m[k];
 }
 static inline uint32_t dropout_threshold(float p) {
     if (p <= 0.f) return 0u;

@@ -79,8 +79,10 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__
             for (int k = 0; k < VN; ++k) o.set(k, v.get(k) + pos[(int64_t)t * d + c0 + k]);
         }
         if (thresh) {
+            float mk[VN];   // d and c0 are multiples of VN: the run starts on an even element
+            dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
 #pragma unroll
-            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * dropout_mult(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c0 + k), thresh, inv_keep));
+            for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * mk[k]);
         }
         st16(X + row * d + c0, o);
     }
@@ -103,8 +105,10 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T *__restrict__ dX
         const int64_t row = (int64_t)b * N + t;
         Vec16<T> v = ld16(dX + row * d + c0);
         if (thresh) {
+            float mk[VN];
+            dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
 #pragma unroll
-            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint32_t)row * (uint32_t)d + (uint32_t)(c0 + k), thresh, inv_keep));
+            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
         }
 #pragma unroll
         for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
@@ -237,13 +241,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
                 if (EXTRA) {
                     if (thresh) {
                         Vec16<T> om;
+                        float mk[VN];
+                        dropout_maskN<VN>(seed, (uint32_t)r * (uint32_t)d + (uint32_t)c, thresh, inv_keep, mk);
 #pragma unroll
-                        for (int k = 0; k < VN; k += 2) {
-                            float m0, m1;
-                            dropout_pair(seed, (uint32_t)r * (uint32_t)d + (uint32_t)(c + k), thresh, inv_keep, m0, m1);
-                            om.set(k, o.get(k) * m0);
-                            om.set(k + 1, o.get(k + 1) * m1);
-                        }
+                        for (int k = 0; k < VN; ++k) om.set(k, o.get(k) * mk[k]);
                         st16(dxm + r * d + c, om);
 #pragma unroll
                         for (int k = 0; k < VN; ++k) ac[i][k] += om.get(k);
@@ -376,8 +377,10 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const T *__restrict_
     const int64_t nv = count / VN;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         Vec16<T> v = ld16(in + i * VN);
+        float mk[VN];
+        dropout_maskN<VN>(seed, (uint32_t)i * (uint32_t)VN, thresh, inv_keep, mk);
 #pragma unroll
-        for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * dropout_mult(seed, (uint32_t)i * (uint32_t)VN + (uint32_t)k, thresh, inv_keep));
+        for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
         st16(out + i * VN, v);
     }
 }

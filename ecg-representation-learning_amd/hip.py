@@ -12,7 +12,7 @@ from ctypes import c_int, c_int32, c_int64, c_uint64, c_float, c_void_p, c_char_
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')
+LIB_PATH = os.environ.get('ECGVIT_HIP_LIB') or os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # env: A/B another build of the same ABI
 
 F32, BF16 = 0, 1
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2

@@ -666,3 +666,32 @@ def test_gemm_bf16_saved_gelu_grad_and_mul_aux(shape):
     D = torch.zeros(M, N, device='cuda', dtype=BF16)
     hip.gemm(hip.GEMM_NT, dev(dY), dev(W), D, M, N, K, K, K, N, epilogue=hip.EPI_MUL_AUX, aux=aux2, ldaux=N)
     assert rel_err(D, _gemm_ref(hip.GEMM_NT, dY.float(), W.float()) * aux2.float().double().cpu()) < 4e-3
+
+
+def test_dropout_mask_statistics():
+    """the counter-based mask (one Weyl step + one xorshift-multiply round per pair of elements): keep rate, independence of neighbours
+    along a row, across rows and across seeds -- on 4M elements the standard error of a correlation is 5e-4"""
+    rows, d = 4096, 1024
+    ones = torch.ones(rows * d, device='cuda')
+    masks = []
+    for p, seed in ((0.1, 1), (0.1, 2), (0.5, 123456789012345), (0.25, 7)):
+        out = torch.empty_like(ones)
+        check(lib().ecgvit_dropout_apply(ptr(ones), ptr(out), rows * d, p, seed, hip.F32, stream()), 'dropout_apply')
+        keep = (out != 0).float().view(rows, d)
+        assert abs(float(keep.mean()) - (1 - p)) < 2e-3, (p, float(keep.mean()))
+        assert torch.allclose(out[out != 0], torch.tensor(1.0 / (1 - p), device='cuda'))
+        z = keep - keep.mean()
+        var = float((z * z).mean())
+
+        def corr(a, b):
+            return float((a * b).mean()) / var
+        assert abs(corr(z[:, :-1], z[:, 1:])) < 4e-3            # neighbours (half of them share a hash: the two 16-bit halves)
+        assert abs(corr(z[:, :-2], z[:, 2:])) < 4e-3            # next pair (one Weyl step apart)
+        assert abs(corr(z[:-1, :], z[1:, :])) < 4e-3            # next row (d/2 Weyl steps apart)
+        assert abs(corr(z[:, :-64], z[:, 64:])) < 4e-3
+        colmean, rowmean = keep.mean(0), keep.mean(1)             # no column or row is systematically kept / dropped
+        assert float((colmean - (1 - p)).abs().max()) < 5 * (p * (1 - p) / rows) ** 0.5 + 1e-3
+        assert float((rowmean - (1 - p)).abs().max()) < 5 * (p * (1 - p) / d) ** 0.5 + 1e-3
+        masks.append(keep)
+    z0, z1 = masks[0] - masks[0].mean(), masks[1] - masks[1].mean()
+    assert abs(float((z0 * z1).mean()) / float((z0 * z0).mean())) < 4e-3   # seeds 1 and 2: unrelated masks
