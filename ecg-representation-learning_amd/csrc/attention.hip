@@ -440,6 +440,361 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
     }
 }
 
+// =====================================================================================================
+// backward, persistent (128 < N <= 256): one 512-thread block per CU walks (record, head) items.
+// The one-item-per-block kernel above spends 42 % of its time with the matrix cores idle -- every block first waits for
+// 190 KiB of inputs (a CU ingests ~11 B/cycle from a cold start) and ends with 64 KiB of dK / dV stores, and its 130 KiB of LDS
+// leave no room for a second block to hide either.  Here the inputs are a STREAM that never drains:
+//   * Q / dO / O arrive as 32-query slabs (3 x 4 KiB) through a four-slot ring, DMA'd three query blocks ahead of their use --
+//     across the item boundary, so the next (record, head)'s first slabs are already in LDS when the current one finishes;
+//   * the K image is double-buffered (the next item's K, its V fragments and LSE row are fetched during query block 1);
+//   * delta = rowsum(dO * O) is computed per slab, cooperatively, one query block ahead;
+//   * ONE counted wait (vmcnt) and ONE barrier per query block: a wave waits only for its own DMA pieces of slab j+2 while the
+//     youngest operations (the slab just issued, the previous dQ store) stay in flight;
+//   * dK / dV leave through per-wave 4-KiB patches in the dS buffers; their stores are still in flight when the next item starts.
+// Math, fragment layouts, dropout indexing and the dQ tile scheme are those of the kernel above.
+__device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit_debug_attn_stamps): per-block cycle stamps, else null
+
+// Transposed LDS read issued as inline asm: hipcc's waitcnt pass cannot see through the builtin whether an LDS-DMA still in flight
+// aliases the read and drains vmcnt(0) in front of it -- fatal for a kernel whose operand stream is never supposed to drain.  The
+// asm form is invisible to that pass; the caller orders it by hand (s_waitcnt lgkmcnt + sched_barrier before the consumer).
+__device__ __forceinline__ bf16x4 tr_read_asm(uint32_t lds_addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ bf16x4 tr_read_asm_o(uint32_t lds_addr) {   // immediate offset: no address VALU
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
+// two f32 -> one dword of two bf16 (v_cvt_pk_bf16_f32): explicit pairs, so every accumulator value is converted exactly once
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    f32x2_t v; v[0] = a; v[1] = b;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
+
+template <bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
+                                                            const bf16_t *__restrict__ dout, const float *__restrict__ lse,
+                                                            bf16_t *__restrict__ dqkv, int N, int h, float scale, uint64_t seed,
+                                                            uint32_t thresh, float inv_keep, int nitems) {
+    constexpr int NKT = 8, NK = 256, IMG = 32768, DSB = 16384, SLAB = 12288;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * IMG + 4 * SLAB + 2 * DSB + 2 * NK * 4 + 2 * 32 * 4];
+    char *const Kimg0 = smem, *const slab0 = smem + 2 * IMG, *const dSimg = slab0 + 4 * SLAB;
+    float *const lse_s = reinterpret_cast<float *>(dSimg + 2 * DSB), *const delta_s = lse_s + 2 * NK;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int mykey = wave * 32 + lr;
+    const bool late = wave >= 4;
+    const int d = h * 64;
+    const int d3 = 3 * d;
+    const int nqb = (N + 31) >> 5;
+    const float c = scale * 1.44269504088896340736f;
+    const RowOff ro = make_row_off(lane);
+    const TrOff to = make_tr_off(lane);
+    const int dq_g = lane >> 4, dq_i = lane & 15;
+    const int dq_key = 4 * dq_g + (dq_i >> 2);
+    const int dq_a[2] = {dq_key * 64 + (((0 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3), dq_key * 64 + (((1 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3)};
+    int dq_b[4];
+#pragma unroll
+    for (int dhc = 0; dhc < 4; ++dhc) dq_b[dhc] = img_off(dq_key, (dhc * 16 + (dq_i & 3) * 4) * 2);
+
+    // per-lane DMA source offsets (bytes): a piece = 8 image rows; the image swizzle is applied to the SOURCE chunk
+    const int prow = (wave & 3) * 8 + (lane >> 3);                          // slab piece row (0..31)
+    const int pchunk = ((lane & 7) ^ swz3(prow)) * 16;
+    const int vo_q = prow * d3 * 2 + pchunk, vo_d = prow * d * 2 + pchunk;  // Q (row pitch 3d) ; dO / O (row pitch d)
+    int vo_k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        vo_k[i] = row * d3 * 2 + (((lane & 7) ^ swz3(row)) * 16);
+    }
+    const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_d = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
+
+    struct Item { const bf16_t *q, *o, *dO; int bh, b, hd; };
+    auto make_item = [&](int it) {
+        Item x;
+        x.bh = it; x.b = it / h; x.hd = it - x.b * h;
+        x.q = qkv + (int64_t)x.b * N * d3 + x.hd * 64;
+        x.o = out + (int64_t)x.b * N * d + x.hd * 64;
+        x.dO = dout + (int64_t)x.b * N * d + x.hd * 64;
+        return x;
+    };
+    // slab qb of item x -> ring slot: waves 0-3 move one Q piece and one O piece each, waves 4-7 one dO piece each
+    auto dma_slab = [&](const Item &x, int qb, int slot) {
+        char *dst = slab0 + slot * SLAB + (wave & 3) * 1024;
+        if (!late) {
+            const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void *)x.q, 0, bytes_q, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rO = __builtin_amdgcn_make_buffer_rsrc((void *)x.o, 0, bytes_d, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void_p)dst, 16, vo_q, qb * 32 * d3 * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rO, (lds_void_p)(dst + 8192), 16, vo_d, qb * 32 * d * 2, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)x.dO, 0, bytes_d, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_p)(dst + 4096), 16, vo_d, qb * 32 * d * 2, 0, 0);
+        }
+    };
+    auto dma_k = [&](const Item &x, char *img) {
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + d), 0, bytes_q, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, vo_k[i], 0, 0, 0);
+    };
+    // Every global access below is a bounds-checked BUFFER operation on a per-item descriptor (rows >= N read zero / are dropped by
+    // the hardware): no lane predicate, so each wave issues the same number of memory instructions whatever N is -- the counted
+    // waits in the loop depend on it.
+    auto load_v = [&](const Item &x, bf16x8 (&v)[4]) {
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + 2 * d), 0, bytes_q, 0x00020000);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            v[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (mykey * d3 + ks * 16 + 8 * lh) * 2, 0, 0));
+    };
+    auto load_lse = [&](const Item &x) {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)(lse + (int64_t)x.bh * N), 0, (uint32_t)N * 4u, 0x00020000);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)(threadIdx.x & 255) * 4, 0, 0));   // scaled by log2(e) when stored
+    };
+    // delta of the slab in ring slot `slot` -> delta_s[buf][32]: wave w owns rows 4w..4w+3, 16 lanes per row, 4 elements per lane
+    auto slab_delta = [&](int slot, int buf) {
+        const int row = wave * 4 + (lane >> 4), e = (lane & 15) * 4;
+        const char *sb = slab0 + slot * SLAB;
+        const bf16x4 a = *reinterpret_cast<const bf16x4 *>(sb + 4096 + img_off(row, e * 2));
+        const bf16x4 o = *reinterpret_cast<const bf16x4 *>(sb + 8192 + img_off(row, e * 2));
+        float acc = (float)a[0] * (float)o[0] + (float)a[1] * (float)o[1] + (float)a[2] * (float)o[2] + (float)a[3] * (float)o[3];
+        // 16-lane row reduction with DPP row shifts (no LDS crossbar): lane 15 of each row ends with the sum
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x118, 0xF, 0xF, true));   // row_shr:8
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x114, 0xF, 0xF, true));   // row_shr:4
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x112, 0xF, 0xF, true));   // row_shr:2
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x111, 0xF, 0xF, true));   // row_shr:1
+        if ((lane & 15) == 15) delta_s[buf * 32 + row] = acc;
+    };
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    Item cur = make_item(it), nxt = cur;
+    bf16x8 vf[4], vfn[4];
+    float lse_n = 0.f;
+    // ---- prologue of the block's first item: K, V, LSE, slabs 0..2
+    dma_k(cur, Kimg0);
+    load_v(cur, vf);
+    {
+        const float l0 = load_lse(cur);
+        dma_slab(cur, 0, 0);
+        dma_slab(cur, 1, 1);
+        dma_slab(cur, 2, 2);
+        if (threadIdx.x < 256) lse_s[threadIdx.x] = l0 * 1.44269504088896340736f;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    slab_delta(0, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
+    int item_no = 0;
+    int slot = 0, par = 0, jj = 0;   // ring slot of the current slab, K / LSE buffer of the current item, running slab counter (delta / dS parity)
+    for (;;) {
+        const int next_it = it + (int)gridDim.x;
+        const bool has_next = next_it < nitems;
+        if (has_next) nxt = make_item(next_it);
+        const char *Kimg = Kimg0 + par * IMG;
+        const float *lse_c = lse_s + par * NK;
+        f32x16 dKt[2], dVt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dKt[dt][r] = 0.f; dVt[dt][r] = 0.f; }
+
+        if (stamps && threadIdx.x == 0 && item_no < 4) stamps[item_no * 32] = __builtin_amdgcn_s_memtime();
+        for (int qb = 0; qb < nqb; ++qb, ++jj) {
+            // ---- feed the stream: next item's K / V / LSE once, slab qb+3 (of this item or the first slabs of the next)
+            if (has_next && qb == 1) {
+                dma_k(nxt, Kimg0 + (par ^ 1) * IMG);
+                lse_n = load_lse(nxt);
+            }
+            if (qb + 3 < nqb) dma_slab(cur, qb + 3, (slot + 3) & 3);
+            else if (has_next) dma_slab(nxt, qb + 3 - nqb, (slot + 3) & 3);
+            // delta of the NEXT slab (visible since the previous barrier), published by this iteration's barrier
+            slab_delta((slot + 1) & 3, (jj + 1) & 1);
+
+            const char *Qrow = slab0 + slot * SLAB, *dOrow = Qrow + 4096;
+            const float *delta_c = delta_s + (jj & 1) * 32;
+            const uint32_t hstep = (uint32_t)((N + 1) >> 1) * ECGVIT_WEYL;
+            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)(mykey >> 1)) * ECGVIT_WEYL;
+            const uint32_t podd = (uint32_t)(lane & 1);
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {   // K fragments of this wave's 32 keys come from the image every time (4 reads): 16 VGPRs less
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Qrow, ro.ks[ks]), row_frag_c(Kimg + wave * 4096, ro.ks[ks]), s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(dOrow, ro.ks[ks]), vf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_c[qb * 32 + 8 * g4 + 4 * lh]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_c[8 * g4 + 4 * lh]);
+                uint32_t hk[4];
+                if constexpr (DROP) {
+                    const uint32_t hg = hq0 + (uint32_t)(8 * g4 + 4 * lh) * hstep + (podd * 2u) * hstep;
+                    const uint32_t mine0 = pair_finish(hg), mine1 = pair_finish(hg + hstep);
+                    // queries k = 0, 1 were hashed by the even lane of each key pair, k = 2, 3 by the odd lane: quad_perm broadcasts
+                    hk[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xA0, 0xF, 0xF, true);   // quad_perm:[0,0,2,2]
+                    hk[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xA0, 0xF, 0xF, true);
+                    hk[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xF5, 0xF, 0xF, true);   // quad_perm:[1,1,3,3]
+                    hk[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xF5, 0xF, 0xF, true);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * g4 + k;
+                    float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
+                    float g = dp[r];
+                    if constexpr (DROP) {
+                        const float mlt = ((hk[k] >> (podd * 16u)) & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+                        g *= mlt;
+                        s[r] = p * mlt;
+                    } else {
+                        s[r] = p;
+                    }
+                    dp[r] = p * (g - d4[k]) * scale;
+                }
+            }
+            uint32_t Pk[8], Dk[8];   // bf16 pairs (2m, 2m+1) of P (dropped) and dS: MFMA B operands AND the dS^T image rows
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { Pk[m] = cvt_pk_bf16(s[2 * m], s[2 * m + 1]); Dk[m] = cvt_pk_bf16(dp[2 * m], dp[2 * m + 1]); }
+            {
+                uint32_t qa[4], da[4];
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    qa[2 * dt] = lds_addr_of(Qrow) + to.lo[dt]; qa[2 * dt + 1] = lds_addr_of(Qrow) + to.hi[dt];
+                    da[2 * dt] = lds_addr_of(dOrow) + to.lo[dt]; da[2 * dt + 1] = lds_addr_of(dOrow) + to.hi[dt];
+                }
+#define TRG(SS)                                                                                                             \
+                {                                                                                                           \
+                    bf16x4 t[8];                                                                                            \
+                    t[0] = tr_read_asm_o<SS * 2048>(da[0]); t[1] = tr_read_asm_o<SS * 2048>(da[1]);                         \
+                    t[2] = tr_read_asm_o<SS * 2048>(qa[0]); t[3] = tr_read_asm_o<SS * 2048>(qa[1]);                         \
+                    t[4] = tr_read_asm_o<SS * 2048>(da[2]); t[5] = tr_read_asm_o<SS * 2048>(da[3]);                         \
+                    t[6] = tr_read_asm_o<SS * 2048>(qa[2]); t[7] = tr_read_asm_o<SS * 2048>(qa[3]);                         \
+                    u32x4 pu, du;                                                                                           \
+                    pu[0] = Pk[4 * SS]; pu[1] = Pk[4 * SS + 1]; pu[2] = Pk[4 * SS + 2]; pu[3] = Pk[4 * SS + 3];             \
+                    du[0] = Dk[4 * SS]; du[1] = Dk[4 * SS + 1]; du[2] = Dk[4 * SS + 2]; du[3] = Dk[4 * SS + 3];             \
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), dsf = __builtin_bit_cast(bf16x8, du);                 \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+                    __builtin_amdgcn_sched_barrier(0);                                                                      \
+                    dVt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[0], t[1]), pf, dVt[0], 0, 0, 0);         \
+                    dKt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[2], t[3]), dsf, dKt[0], 0, 0, 0);        \
+                    dVt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[4], t[5]), pf, dVt[1], 0, 0, 0);         \
+                    dKt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[6], t[7]), dsf, dKt[1], 0, 0, 0);        \
+                }
+                TRG(0)
+                TRG(1)
+#undef TRG
+            }
+            char *dsb = dSimg + (jj & 1) * DSB;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 v;
+                v[0] = Dk[2 * g4]; v[1] = Dk[2 * g4 + 1];
+                const int slt = 2 * g4 + lh;
+                *reinterpret_cast<u32x2 *>(dsb + mykey * 64 + ((slt ^ dsw(mykey)) << 3)) = v;
+            }
+            // ---- the iteration's one wait + barrier.  Needed: my DMA pieces of slab qb+2 (issued one iteration ago).  Still allowed in
+            // flight, youngest first: this iteration's slab pieces (2 on waves 0-3, 1 on waves 4-7), the K / LSE prefetch of query
+            // block 1 (4 + 1), the previous dQ store -- or, on an item's first query block, the 8 dK / dV stores + last dQ store.
+            __builtin_amdgcn_sched_barrier(0);
+            if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 1 + qb] = __builtin_amdgcn_s_memtime();
+            if (!has_next) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            } else if (late) {
+                if (qb == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                else if (qb == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            } else {
+                if (qb == 0) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+                else if (qb == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            }
+            if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 9 + qb] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 17 + qb] = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            // the next item's V fragments start travelling in the last query block (s / dp / packs are dead: the registers are free)
+            if (has_next && qb == nqb - 1) load_v(nxt, vfn);
+            // ---- dQ tile of this wave (one 16 x 16 tile: qt = wave&1, dhc = wave>>1), then its store: the iteration's LAST memory operation
+            {
+                const int qt = wave & 1, dhc = wave >> 1;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int aoff = dq_a[qt], boff = dq_b[dhc];
+                const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
+#define DQG(HF)                                                                                                              \
+                {                                                                                                            \
+                    bf16x4 t[8];                                                                                             \
+                    t[0] = tr_read_asm_o<(2 * HF) * 2048>(sa); t[1] = tr_read_asm_o<(2 * HF) * 2048 + 1024>(sa);             \
+                    t[2] = tr_read_asm_o<(2 * HF) * 4096>(ka); t[3] = tr_read_asm_o<(2 * HF) * 4096 + 2048>(ka);             \
+                    t[4] = tr_read_asm_o<(2 * HF + 1) * 2048>(sa); t[5] = tr_read_asm_o<(2 * HF + 1) * 2048 + 1024>(sa);     \
+                    t[6] = tr_read_asm_o<(2 * HF + 1) * 4096>(ka); t[7] = tr_read_asm_o<(2 * HF + 1) * 4096 + 2048>(ka);     \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+                    __builtin_amdgcn_sched_barrier(0);                                                                       \
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[2], t[3]), join_halves(t[0], t[1]), acc, 0, 0, 0); \
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[6], t[7]), join_halves(t[4], t[5]), acc, 0, 0, 0); \
+                }
+                DQG(0) DQG(1) DQG(2) DQG(3)
+#undef DQG
+                const int q = qb * 32 + qt * 16 + dq_i;
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
+                const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
+            }
+            slot = (slot + 1) & 3;
+        }
+        if (stamps && threadIdx.x == 0 && item_no < 4) stamps[item_no * 32 + 25] = __builtin_amdgcn_s_memtime();
+        // ---- item done: dK^T / dV^T (dh on rows, key on the lane) -> this wave's 32 [key][dh] rows in a private 4-KiB patch -> 128-B rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave is done reading both dS buffers
+        {
+            char *patch = dSimg + wave * 4096;
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        bf16x4 a;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] = (bf16_t)(which == 0 ? dKt[dt][4 * g4 + k] : dVt[dt][4 * g4 + k]);
+                        *reinterpret_cast<bf16x4 *>(patch + img_off(lr, (dt * 32 + 8 * g4 + 4 * lh) * 2)) = a;
+                    }
+                // same-wave LDS operations execute in order: read the rows back (8 rows x 128 B per instruction) and store them
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + (lane >> 3), ch = lane & 7;
+                    const int key = wave * 32 + row;
+                    const u32x4 val = *reinterpret_cast<const u32x4 *>(patch + img_off(row, ch * 16));
+                    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + (1 + which) * d + cur.hd * 64), 0, bytes_q, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(val, rkv, (key * d3 + ch * 8) * 2, 0, 0);   // keys >= N: dropped
+                }
+            }
+        }
+        if (stamps && threadIdx.x == 0 && item_no < 4) stamps[item_no * 32 + 26] = __builtin_amdgcn_s_memtime();
+        ++item_no;
+        if (!has_next) break;
+        // ---- switch to the next item: its K image and LSE row were fetched during query block 1, its V fragments during the drain
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = vfn[ks];
+        if (threadIdx.x < 256) lse_s[(par ^ 1) * NK + threadIdx.x] = lse_n * 1.44269504088896340736f;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // patches drained (the next dS write may reuse them); LSE row visible
+        par ^= 1;
+        it = next_it;
+        cur = nxt;
+    }
+}
+
 // probe: exact-integer dump of what each lane receives from the fragment helpers (tests pin the layouts with it)
 __global__ __launch_bounds__(64) void probe_kernel(float *out) {
     __shared__ __attribute__((aligned(16))) char img[64 * 128];
@@ -511,6 +866,10 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t *__restric
 
 extern "C" {
 
+int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 256 blocks x 128 uint64 cycle stamps written by the persistent backward; NULL = off
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf)) == hipSuccess ? ECGVIT_OK : ECGVIT_ELAUNCH;
+}
+
 int ecgvit_attention_probs(const void *qkv, const float *lse, float *probs, int B, int N, int h, int dh, float scale, int dtype, void *stream) {
     if (dtype != ECGVIT_BF16 || dh % 8 || B <= 0 || N <= 0 || h <= 0 || (int64_t)B * h > 65535) return ECGVIT_EINVAL;
     hipLaunchKernelGGL(attn_probs_kernel, dim3((N + 3) / 4, B * h), dim3(256), 0, as_stream(stream), (const bf16_t *)qkv, lse, probs, N, h, dh, scale);
@@ -546,6 +905,16 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     dim3 grid((unsigned)(B * h));
     static const int ablate = [] { const char *e = getenv("ECGVIT_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // diagnostics only
+    const char *pe = getenv("ECGVIT_ATTN_PERSIST");   // read per call: tests compare both kernels in one process
+    const bool pers = !(pe && pe[0] == '0');
+    if (pers && N > 128 && !ablate && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31)) {
+        const int nitems = B * h;
+        const dim3 pg((unsigned)(nitems < 256 ? nitems : 256));
+        if (th) hipLaunchKernelGGL(attn_bwd_pers_kernel<true>, pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems);
+        else hipLaunchKernelGGL(attn_bwd_pers_kernel<false>, pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems);
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
 #define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, ablate)
     if (N <= 128) { if (th) BWD(4, true); else BWD(4, false); }
     else { if (th) BWD(8, true); else BWD(8, false); }

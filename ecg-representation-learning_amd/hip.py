@@ -80,6 +80,7 @@ SIGNATURES = {
     'ecgvit_l1_loss_fwd_bwd': (c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P]),
     'ecgvit_eval_counts': (c_int, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P]),
     'ecgvit_probe_mfma_layout': (c_int, [_P, _P]),
+    'ecgvit_debug_attn_stamps': (c_int, [_P]),
 }
 
 _lib = None

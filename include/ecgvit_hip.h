@@ -240,6 +240,9 @@ int ecgvit_eval_counts(const float *scores, int64_t ld_scores, const float *labe
  * probes used by tests to pin hardware fragment layouts with exact integer data
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_probe_mfma_layout(float *out /* [4][64][16] */, void *stream);
+/* diagnostics: device buffer of 256 x 128 uint64 that the persistent attention backward fills with per-item / per-query-block cycle stamps
+ * (tools/attn_stamps.py); NULL switches it off. The only global state in the library, never set by the product path. */
+int ecgvit_debug_attn_stamps(void *buf);
 
 #ifdef __cplusplus
 }

@@ -695,3 +695,43 @@ def test_dropout_mask_statistics():
         masks.append(keep)
     z0, z1 = masks[0] - masks[0].mean(), masks[1] - masks[1].mean()
     assert abs(float((z0 * z1).mean()) / float((z0 * z0).mean())) < 4e-3   # seeds 1 and 2: unrelated masks
+
+
+@pytest.mark.parametrize('B,h,N,p', [(24, 12, 251, 0.0), (45, 6, 200, 0.0), (64, 5, 130, 0.0), (40, 12, 251, 0.2), (90, 3, 256, 0.1)])
+def test_attention_bwd_persistent_stream(B, h, N, p):
+    """the persistent backward (slab stream continuous across (record, head) items, counted waits, 1-3 items per workgroup) against
+    the double-precision reference (p = 0) and against the one-item-per-workgroup kernel on the same dropout mask (p > 0);
+    ragged N (a whole wave of keys out of range at N = 200 / 130), repeated launches bit-identical (a stream race would show)"""
+    import os
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    dh = 64
+    d = h * dh
+    scale = dh ** -0.5
+    qkv = (torch.randn(B * N, 3 * d, generator=g) * 1.2).to(BF16)
+    do = torch.randn(B * N, d, generator=g).to(BF16)
+    qd, dod = dev(qkv), dev(do)
+    out = torch.empty(B * N, d, device='cuda', dtype=BF16)
+    lse = torch.zeros(B * h * N, device='cuda')
+    check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_fwd')
+
+    def bwd(persist):
+        os.environ['ECGVIT_ATTN_PERSIST'] = '1' if persist else '0'
+        r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=BF16)
+        check(lib().ecgvit_attention_bwd(ptr(qd), ptr(out), ptr(dod), ptr(lse), ptr(r), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_bwd')
+        torch.cuda.synchronize()
+        return r
+    try:
+        new = bwd(True)
+        assert torch.isfinite(new.float()).all()
+        for _ in range(5):
+            assert torch.equal(bwd(True), new)
+        old = bwd(False)
+        assert rel_err(new, old.float().double().cpu()) < 2e-3
+    finally:
+        os.environ.pop('ECGVIT_ATTN_PERSIST', None)
+    if p == 0.0:
+        qr = qkv.double().requires_grad_(True)
+        o_ref, _, _ = _attn_ref(qr, B, N, h, dh, scale)
+        o_ref.backward(do.double())
+        for i, nm in enumerate('qkv'):
+            assert rel_err(new[:, i * d:(i + 1) * d], qr.grad[:, i * d:(i + 1) * d]) < 2e-2, nm
