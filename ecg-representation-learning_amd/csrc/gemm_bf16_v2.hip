@@ -1284,19 +1284,30 @@ __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__rest
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, int nparts, int N, float *__restrict__ out) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float *__restrict__ partial, int nparts, int N, float *__restrict__ out) {
+    // 64 columns x 16 row slices per block (N/64 blocks only: the parallelism comes from inside the block); deterministic tree
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < N) {
         int p = slice;
-        for (; p + 4 < nparts; p += 8) { s0 += partial[(int64_t)p * N + c]; s1 += partial[(int64_t)(p + 4) * N + c]; }
-        for (; p < nparts; p += 4) s0 += partial[(int64_t)p * N + c];
+        for (; p + 48 < nparts; p += 64) {
+            s0 += partial[(int64_t)p * N + c];
+            s1 += partial[(int64_t)(p + 16) * N + c];
+            s2 += partial[(int64_t)(p + 32) * N + c];
+            s3 += partial[(int64_t)(p + 48) * N + c];
+        }
+        for (; p < nparts; p += 16) s0 += partial[(int64_t)p * N + c];
     }
-    red[slice][lane] = s0 + s1;
+    red[slice][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (slice == 0 && c < N) out[c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (slice == 0 && c < N) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) { t[0] += red[r][lane]; t[1] += red[r + 1][lane]; t[2] += red[r + 2][lane]; t[3] += red[r + 3][lane]; }
+        out[c] = (t[0] + t[1]) + (t[2] + t[3]);
+    }
 }
 
 inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
@@ -1389,7 +1400,7 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
         else hipLaunchKernelGGL(gemm_bf16_q_kernel<float>, pgrid, block, 0, s, *d, e, sk, tiles_m, tiles_n, nitems);
         ECGVIT_CHECK_LAUNCH();
         if (d->epilogue & ECGVIT_EPI_COLSUM) {
-            hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(256), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
+            hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(1024), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
             ECGVIT_CHECK_LAUNCH();
         }
         return ECGVIT_OK;
@@ -1417,7 +1428,7 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
 #undef LAUNCH
     ECGVIT_CHECK_LAUNCH();
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
-        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(256), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
+        hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(1024), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
         ECGVIT_CHECK_LAUNCH();
     }
     if (sk.splits > 1) {

@@ -88,36 +88,54 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__
     }
 }
 
-// dtok copy + dpos/dcls reductions over the batch. One thread per (token t, 16-B column chunk), loop over b.
+// dtok copy + dpos/dcls reductions over the batch.  One block per (token t, group of 8 16-B column chunks): 8 chunk columns x 32 batch
+// lanes; every thread walks its batch residue class (b = lane, lane + 32, ...), then a fixed-order LDS tree over the 32 lanes --
+// deterministic, and N * d/(8 VN) blocks of 256 threads instead of one sequential 512-deep loop per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const T *__restrict__ dX, T *__restrict__ dtok, float *__restrict__ dcls,
                                                         float *__restrict__ dpos, int B, int n, int d, uint64_t seed,
                                                         uint32_t thresh, float inv_keep) {
     constexpr int VN = Vec16<T>::N;
-    const int N = n + 1, dv = d / VN;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * dv) return;
-    const int t = i / dv, c0 = (i - t * dv) * VN;
+    __shared__ float red[32][8 * VN + 1];
+    const int N = n + 1, dv = d / VN, groups = (dv + 7) / 8;
+    const int t = blockIdx.x / groups, cg = blockIdx.x - t * groups;
+    const int cc = threadIdx.x & 7, bl = threadIdx.x >> 3;       // chunk column within the group, batch lane
+    const int chunk = cg * 8 + cc;
+    const bool live = chunk < dv;
+    const int c0 = chunk * VN;
     float acc[VN];
 #pragma unroll
     for (int k = 0; k < VN; ++k) acc[k] = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const int64_t row = (int64_t)b * N + t;
-        Vec16<T> v = ld16(dX + row * d + c0);
-        if (thresh) {
-            float mk[VN];
-            dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
+    if (live) {
+        for (int b = bl; b < B; b += 32) {
+            const int64_t row = (int64_t)b * N + t;
+            Vec16<T> v = ld16(dX + row * d + c0);
+            if (thresh) {
+                float mk[VN];
+                dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
 #pragma unroll
-            for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
+                for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
+            if (t > 0) st16(dtok + ((int64_t)b * n + (t - 1)) * d + c0, v);
         }
-#pragma unroll
-        for (int k = 0; k < VN; ++k) acc[k] += v.get(k);
-        if (t > 0) st16(dtok + ((int64_t)b * n + (t - 1)) * d + c0, v);
     }
 #pragma unroll
-    for (int k = 0; k < VN; ++k) {
-        dpos[(int64_t)t * d + c0 + k] = acc[k];
-        if (t == 0) dcls[c0 + k] = acc[k];
+    for (int k = 0; k < VN; ++k) red[bl][cc * VN + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 8 * VN) {
+        const int col = cg * 8 * VN + threadIdx.x;
+        if (col < d) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 32; r += 4) {
+                s[0] += red[r][threadIdx.x]; s[1] += red[r + 1][threadIdx.x]; s[2] += red[r + 2][threadIdx.x]; s[3] += red[r + 3][threadIdx.x];
+            }
+            const float tot = (s[0] + s[1]) + (s[2] + s[3]);
+            dpos[(int64_t)t * d + col] = tot;
+            if (t == 0) dcls[col] = tot;
+        }
     }
 }
 
@@ -280,27 +298,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
 
 // out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta).
 // Block = 64 columns x 4 row-slices (each slice sums every 4th partial row, 4 loads in flight), LDS combine.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
-                                                              float *__restrict__ out0, float *__restrict__ out1, int split,
-                                                              float *__restrict__ out2 = nullptr) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
+                                                               float *__restrict__ out0, float *__restrict__ out1, int split,
+                                                               float *__restrict__ out2 = nullptr) {
+    // block = 64 columns x 16 row slices (the grid is only width/64 blocks, so the parallelism has to come from inside the block);
+    // every slice sums each 16th partial row with 4 loads in flight; fixed-order LDS tree -> deterministic
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < width) {
         int p = slice;
-        for (; p + 12 < nparts; p += 16) {
+        for (; p + 48 < nparts; p += 64) {
             s0 += partial[(int64_t)p * width + c];
-            s1 += partial[(int64_t)(p + 4) * width + c];
-            s2 += partial[(int64_t)(p + 8) * width + c];
-            s3 += partial[(int64_t)(p + 12) * width + c];
+            s1 += partial[(int64_t)(p + 16) * width + c];
+            s2 += partial[(int64_t)(p + 32) * width + c];
+            s3 += partial[(int64_t)(p + 48) * width + c];
         }
-        for (; p < nparts; p += 4) s0 += partial[(int64_t)p * width + c];
+        for (; p < nparts; p += 16) s0 += partial[(int64_t)p * width + c];
     }
     red[slice][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && c < width) {
-        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; r += 4) { t[0] += red[r][lane]; t[1] += red[r + 1][lane]; t[2] += red[r + 2][lane]; t[3] += red[r + 3][lane]; }
+        const float s = (t[0] + t[1]) + (t[2] + t[3]);
         if (c < split) out0[c] = s;
         else if (c < 2 * split || !out2) out1[c - split] = s;
         else out2[c - 2 * split] = s;
@@ -442,8 +465,8 @@ int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B
     if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0) return ECGVIT_EINVAL;
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
-    const int work = (n + 1) * (d / (dtype == ECGVIT_F32 ? 4 : 8));
-    const int grid = (work + 255) / 256;
+    const int dv = d / (dtype == ECGVIT_F32 ? 4 : 8);
+    const int grid = (n + 1) * ((dv + 7) / 8);   // one block per (token, group of 8 column chunks)
     if (dtype == ECGVIT_F32)
         hipLaunchKernelGGL(embed_bwd_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)dX, (float *)dtok, dcls, dpos, B, n, d, seed, th, ik);
     else if (dtype == ECGVIT_BF16)
@@ -492,7 +515,7 @@ static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, cons
     else { if (nv <= 1) LN_BWD(bf16_t, 1); else if (nv <= 2) LN_BWD(bf16_t, 2); else LN_BWD(bf16_t, 4); }
 #undef LN_BWD
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, grid, np * d, dgamma, dbeta, d, extra ? dcolsum : nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 63) / 64), dim3(1024), 0, as_stream(stream), (const float *)partial, grid, np * d, dgamma, dbeta, d, extra ? dcolsum : nullptr);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
@@ -524,7 +547,7 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t *)in, ld, (float *)partial, M, N, rpb);
     else return ECGVIT_EINVAL;
     ECGVIT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(1024), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
