@@ -308,9 +308,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
         const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
         split = x + 8 * (q % r);
         tid = q / r;
+    } else if (sk.splits > 1) {
+        // split-K with a slice count that is no multiple of 8: remap over ALL (slice, tile) items, so that an XCD's contiguous run is
+        // (almost) one K-slice and its tiles share that slice's operand rows in one L2 (remapping inside a slice spreads it over 8 L2s)
+        const int gid = xcd_remap(blockIdx.x, ntile * sk.splits);
+        split = gid / ntile;
+        tid = gid - split * ntile;
     } else {
-        split = blockIdx.x / ntile;
-        tid = xcd_remap(blockIdx.x - split * ntile, ntile);
+        split = 0;
+        tid = xcd_remap(blockIdx.x, ntile);
     }
     // tile order inside an XCD's contiguous run: n-tiles are taken in groups of sk.ngroup whose B (weight) panels fit the
     // 4-MiB L2, and all m-panels are swept per group -- B is then fetched ~once per XCD instead of once per 32-tile round.
