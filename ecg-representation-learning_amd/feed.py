@@ -1,0 +1,165 @@
+"""
+Record feeding for the train / eval loops: N x 12 x L record arrays -> device batches.
+
+Mirror of what the reference does around the model: `EcgDataset` / `PtbxlDataset` (`ecg_transformer/preprocess/dataset.py:22-99`,
+`preprocess/ptb_dataset.py:53-78`: an HDF5 'data' array of float64 records indexed by PTB-XL csv row, labels as lists of code
+ids -> 71-wide multi-hot), `get_ptbxl_splits` (`ptb_dataset.py:101-133`: `strat_fold` < 9 train, 9 eval, 10 test) and the
+`DataLoader(batch_size, shuffle, pin_memory=True, num_workers=0)` of `PtbxlDataModule` (`:81-98`).  The reference transforms every
+record on the host, one numpy call at a time, in the training process (HDF5 handles cannot be pickled: `num_workers=0`), which caps
+it far below the 5-6 k records/s the MI355X step consumes.  Here the host only GATHERS raw rows (one fancy-index per batch, in a
+background thread) into pinned memory and starts an asynchronous H2D copy on a side stream; Normalize / TimeEndPad / TimeOut run on
+the device inside the patch-embed load (`transform.FusedInputTransform`), labels are expanded to multi-hot once, up front.
+
+HDF5 needs `h5py` (absent from this image: the import is attempted only when an `.h5/.hdf5` path is given); `.npy` files are
+memory-mapped; arrays are used as they are.
+"""
+import os
+import threading
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+PtbxlSplits = namedtuple('PtbxlSplits', ['train', 'eval', 'test'])   # index arrays into the record store (0-indexed csv rows)
+N_CLASS = 71
+
+
+def open_records(source):
+    """(N, C, L) record array: ndarray / memmap as is, '*.npy' memory-mapped, '*.h5|*.hdf5' -> its 'data' dataset (needs h5py)"""
+    if isinstance(source, str):
+        ext = os.path.splitext(source)[1].lower()
+        if ext == '.npy':
+            return np.load(source, mmap_mode='r')
+        if ext in ('.h5', '.hdf5'):
+            try:
+                import h5py
+            except ImportError as e:
+                raise ImportError('reading the reference\'s HDF5 record files needs h5py, which this environment does not have; '
+                                  'export the "data" dataset to .npy once and pass that path') from e
+            return h5py.File(source, 'r')['data']
+        raise ValueError(f'unsupported record file {source!r}')
+    if getattr(source, 'ndim', 0) != 3:
+        raise ValueError('records must be an (N, C, L) array')
+    return source
+
+
+def ptbxl_splits(strat_fold, n_sample=None) -> PtbxlSplits:
+    """`get_ptbxl_splits`: folds 1-8 train, 9 eval, 10 test; `n_sample` keeps the first rows of each split (ptb_dataset.py:111-113)"""
+    f = np.asarray(strat_fold)
+    tr, vl, ts = np.nonzero(f < 9)[0], np.nonzero(f == 9)[0], np.nonzero(f == 10)[0]
+    if n_sample is not None:
+        tr, vl, ts = tr[:n_sample], vl[:n_sample], ts[:n_sample]
+    else:
+        assert len(tr) + len(vl) + len(ts) == len(f)   # the reference's own sanity check: folds are in [1, 10]
+    return PtbxlSplits(tr, vl, ts)
+
+
+def lbs2multi_hot(labels, n_class=N_CLASS):
+    """`PtbxlDataset.lbs2multi_hot(return_float=True)` for a whole split at once: list of code-id lists -> (n, n_class) float32"""
+    out = np.zeros((len(labels), n_class), dtype=np.float32)
+    for i, lb in enumerate(labels):
+        out[i, list(lb)] = 1.0
+    return out
+
+
+class DeviceFeeder:
+    """Iterate `dict(sample_values=(b, C, L) f32, labels=(b, K) f32)` device batches over `records[idxs]` (raw, untransformed).
+
+    Double-buffered: while the step consumes batch i, a worker thread gathers batch i+1 from the (memory-mapped) store into pinned
+    memory (float64 -> float32 as the reference's `__getitem__` does) and queues its H2D copy on a side stream; the consumer's stream
+    waits on the copy's event only.  `shuffle` permutes with `torch.randperm` per epoch (seeded); `rank/world` take a contiguous
+    shard of every epoch's order (`ddp.shard_range` semantics).  On a CPU-only host (tests) it degrades to synchronous host tensors.
+    """
+
+    def __init__(self, records, idxs, labels_multi_hot, batch_size, shuffle=False, seed=77, device=None, rank=0, world=1,
+                 drop_last=False):
+        self.rec = open_records(records)
+        self.idxs = np.asarray(idxs, dtype=np.int64)
+        self.labels = np.ascontiguousarray(labels_multi_hot, dtype=np.float32)
+        assert len(self.idxs) == len(self.labels)
+        self.bsz, self.shuffle, self.seed, self.drop_last = int(batch_size), shuffle, seed, drop_last
+        self.rank, self.world = rank, world
+        self.device = torch.device(device) if device is not None else torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.on_gpu = self.device.type == 'cuda'
+        self.epoch = 0
+        _, self.C, self.L = self.rec.shape
+
+    def __len__(self):
+        n = self._shard_len()
+        return n // self.bsz if self.drop_last else (n + self.bsz - 1) // self.bsz
+
+    def _shard_len(self):
+        n = len(self.idxs)
+        lo, hi = (self.rank * n) // self.world, ((self.rank + 1) * n) // self.world
+        return hi - lo
+
+    def _order(self):
+        n = len(self.idxs)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=g).numpy()
+        else:
+            perm = np.arange(n)
+        lo, hi = (self.rank * n) // self.world, ((self.rank + 1) * n) // self.world
+        return perm[lo:hi]
+
+    def _gather(self, rows, x_buf, y_buf):
+        b = len(rows)
+        src = self.idxs[rows]
+        order = np.argsort(src, kind='stable')                   # HDF5 / memmap fancy indexing wants increasing indices
+        tmp = np.asarray(self.rec[src[order]] if hasattr(self.rec, 'id') else self.rec[src[order]])
+        inv = np.empty_like(order)
+        inv[order] = np.arange(b)
+        x_buf[:b].numpy()[...] = tmp[inv]                        # float64 -> float32 happens in this assignment
+        y_buf[:b].numpy()[...] = self.labels[rows]
+        return b
+
+    def __iter__(self):
+        order = self._order()
+        self.epoch += 1
+        nb = len(self)
+        bounds = [(i * self.bsz, min((i + 1) * self.bsz, len(order))) for i in range(nb)]
+        if not self.on_gpu:
+            for lo, hi in bounds:
+                x = torch.empty(hi - lo, self.C, self.L)
+                y = torch.empty(hi - lo, self.labels.shape[1])
+                self._gather(order[lo:hi], x, y)
+                yield dict(sample_values=x, labels=y)
+            return
+        pin = [(torch.empty(self.bsz, self.C, self.L).pin_memory(), torch.empty(self.bsz, self.labels.shape[1]).pin_memory()) for _ in range(2)]
+        dev = [(torch.empty(self.bsz, self.C, self.L, device=self.device), torch.empty(self.bsz, self.labels.shape[1], device=self.device))
+               for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=self.device)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]          # H2D copy of slot s has completed
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]       # the consumer's kernels reading slot s have been queued before this event
+        sizes = [0, 0]
+
+        def produce(i):
+            s = i & 1
+            lo, hi = bounds[i]
+            consumed[s].synchronize()                             # the device no longer reads dev[s] (2 batches ago)
+            sizes[s] = self._gather(order[lo:hi], *pin[s])
+            with torch.cuda.stream(copy_stream):
+                dev[s][0][:sizes[s]].copy_(pin[s][0][:sizes[s]], non_blocking=True)
+                dev[s][1][:sizes[s]].copy_(pin[s][1][:sizes[s]], non_blocking=True)
+                ready[s].record(copy_stream)
+
+        for e in consumed:
+            e.record()
+        worker = None
+        if nb:
+            produce(0)
+        for i in range(nb):
+            if worker is not None:
+                worker.join()
+            if i + 1 < nb:
+                worker = threading.Thread(target=produce, args=(i + 1,), daemon=True)
+                worker.start()
+            else:
+                worker = None
+            s = i & 1
+            torch.cuda.current_stream().wait_event(ready[s])
+            yield dict(sample_values=dev[s][0][:sizes[s]], labels=dev[s][1][:sizes[s]])
+            consumed[s].record()                                  # everything the caller queued on its stream for this batch precedes this
+        if worker is not None:
+            worker.join()

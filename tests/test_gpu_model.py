@@ -526,3 +526,41 @@ def test_bf16_input_gradients_via_transposed_shadows_match_plain_path():
     ts.finish()
     for k, wt in eng.WT.items():
         assert torch.equal(wt.t(), eng.W[k]) and torch.equal(eng.W[k], eng.P32[k].to(BF16)), k
+
+
+# ------------------------------------------------------------------------------------------------------ f4: record feeding
+def test_device_feeder_pinned_async_batches_and_fused_transform(tmp_path):
+    """double-buffered pinned H2D feeder: every batch arrives intact and in order over two epochs while the consumer keeps the
+    device busy; feeding RAW records into a model with the fused input transform == transforming on the host first"""
+    rng = np.random.default_rng(1)
+    n, L_raw, k = 150, 990, 20
+    rec = rng.standard_normal((n, 12, L_raw)) * 3 + 1                         # float64 on disk
+    path = os.path.join(tmp_path, 'rec.npy')
+    np.save(path, rec)
+    mh = (rng.random((n, 71)) < 0.05).astype(np.float32)
+    idx = np.arange(n)[::-1].copy()                                           # non-monotonic source rows
+    feeder = E.DeviceFeeder(path, idx, mh, batch_size=32, shuffle=False)
+    want_x, want_y = torch.from_numpy(rec[idx].astype(np.float32)), torch.from_numpy(mh)
+    for _ in range(2):
+        xs, ys = [], []
+        for b in feeder:
+            assert b['sample_values'].is_cuda and b['sample_values'].dtype == F32
+            junk = torch.randn(2048, 2048, device='cuda') @ torch.randn(2048, 2048, device='cuda')   # consumer work between batches
+            xs.append(b['sample_values'].clone()); ys.append(b['labels'].clone())
+        assert torch.equal(torch.cat(xs).cpu(), want_x) and torch.equal(torch.cat(ys).cpu(), want_y)
+    mean, std = rec.mean(axis=(0, 2)).astype(np.float32), rec.std(axis=(0, 2)).astype(np.float32)
+    xf = E.FusedInputTransform(mean, std, patch_size=k)
+    L = xf.padded_length(L_raw)
+    conf = E.EcgVitConfig(max_signal_length=L, patch_size=k, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          intermediate_size=128, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(0)
+    m_raw = E.EcgVit(config=conf).cuda().eval()
+    m_ref = E.EcgVit(config=conf).cuda().eval()
+    m_ref.load_state_dict(m_raw.state_dict())
+    m_raw.set_input_transform(xf)
+    b = next(iter(feeder))
+    host = np.pad((rec[idx[:32]] - mean.reshape(1, -1, 1)) / std.reshape(1, -1, 1), [(0, 0), (0, 0), (0, L - L_raw)]).astype(np.float32)
+    with torch.no_grad():
+        o_raw = m_raw(sample_values=b['sample_values'], labels=b['labels'])
+        o_ref = m_ref(sample_values=torch.from_numpy(host).cuda(), labels=b['labels'])
+    assert max_err(o_raw.logits, o_ref.logits.cpu()) < 1e-4 and abs(float(o_raw.loss) - float(o_ref.loss)) < 1e-5
