@@ -296,6 +296,168 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
     }
 }
 
+// =====================================================================================================
+// bf16 LayerNorm with an EXACT lane mapping (d = 64 * E, E in {4, 8, 12, 16, 24, 32}): every lane owns E = d/64 elements of a
+// row as E/8 16-byte chunks plus, when E % 8 == 4, one 8-byte chunk -- for d = 768 that is 16 B (columns 0..511) + 8 B (columns
+// 512..767) per lane, no half-idle second vector as in the MAXV = 2 mapping above: 25 % fewer registers in the backward (4 waves
+// per SIMD instead of 3 -> more rows in flight) and no masked lanes.
+// =====================================================================================================
+template <int E> struct LaneRow {
+    static constexpr int N16 = E / 8, N8 = (E % 8) / 4;
+    // column of element e of this lane
+    static __device__ __forceinline__ int col(int e, int lane) { return e < 8 * N16 ? ((e >> 3) * 64 + lane) * 8 + (e & 7) : 512 * N16 + 4 * lane + (e - 8 * N16); }
+    static __device__ __forceinline__ void load(const bf16_t *row, int lane, float (&v)[E]) {
+#pragma unroll
+        for (int i = 0; i < N16; ++i) {
+            const Vec16<bf16_t> t = ld16(row + (i * 64 + lane) * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[8 * i + k] = t.get(k);
+        }
+        if constexpr (N8 == 1) {
+            const bf16x4 t = *reinterpret_cast<const bf16x4 *>(row + 512 * N16 + 4 * lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[8 * N16 + k] = (float)t[k];
+        }
+    }
+    static __device__ __forceinline__ void load_f32(const float *row, int lane, float (&v)[E]) {
+#pragma unroll
+        for (int i = 0; i < N16; ++i) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + (i * 64 + lane) * 8), b = *reinterpret_cast<const f32x4 *>(row + (i * 64 + lane) * 8 + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[8 * i + k] = a[k]; v[8 * i + 4 + k] = b[k]; }
+        }
+        if constexpr (N8 == 1) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(row + 512 * N16 + 4 * lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[8 * N16 + k] = a[k];
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t *row, int lane, const float (&v)[E]) {
+#pragma unroll
+        for (int i = 0; i < N16; ++i) {
+            Vec16<bf16_t> t;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t.set(k, v[8 * i + k]);
+            st16(row + (i * 64 + lane) * 8, t);
+        }
+        if constexpr (N8 == 1) {
+            bf16x4 t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] = (bf16_t)v[8 * N16 + k];
+            *reinterpret_cast<bf16x4 *>(row + 512 * N16 + 4 * lane) = t;
+        }
+    }
+};
+
+template <int E>
+__global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, bf16_t *__restrict__ y,
+                                                                float *__restrict__ mean, float *__restrict__ rstd, int64_t rows, float eps) {
+    using L = LaneRow<E>;
+    constexpr int d = 64 * E;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * 4ll + (threadIdx.x >> 6), nw = gridDim.x * 4ll;
+    float gm[E], bt[E];
+    L::load_f32(gamma, lane, gm);
+    L::load_f32(beta, lane, bt);
+    for (int64_t r = wave0; r < rows; r += nw) {
+        float v[E];
+        L::load(x + r * d, lane, v);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) s += v[k];
+        const float mu = wave_sum(s) * (1.0f / d);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) { v[k] -= mu; q += v[k] * v[k]; }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / d) + eps);
+#pragma unroll
+        for (int k = 0; k < E; ++k) v[k] = v[k] * rs * gm[k] + bt[k];
+        L::store(y + r * d, lane, v);
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+
+template <int E, bool EXTRA>
+__global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel(const bf16_t *__restrict__ dy, const bf16_t *__restrict__ x,
+                                                                const float *__restrict__ gamma, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, const bf16_t *__restrict__ dres,
+                                                                bf16_t *__restrict__ dx, float *__restrict__ partial, int64_t rows,
+                                                                bf16_t *__restrict__ dxm, uint64_t seed, uint32_t thresh, float inv_keep) {
+    using L = LaneRow<E>;
+    constexpr int d = 64 * E, NP = EXTRA ? 3 : 2;
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NP][d] partial sums, then gamma [d]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave0 = blockIdx.x * 4ll + w, nw = gridDim.x * 4ll;
+    float *gs = red + 4 * NP * d;   // gamma lives in LDS (3 reads per row) instead of E registers: the kernel fits 128 VGPRs = 4 waves/SIMD
+    for (int c = threadIdx.x; c < d; c += 256) gs[c] = gamma[c];
+    __syncthreads();
+    float ag[E], ab[E], ac[EXTRA ? E : 1];
+#pragma unroll
+    for (int k = 0; k < E; ++k) { ag[k] = 0.f; ab[k] = 0.f; if (EXTRA) ac[k] = 0.f; }
+    for (int64_t r = wave0; r < rows; r += nw) {
+        const float mu = mean[r], rs = rstd[r];
+        const uint32_t ro = (uint32_t)r * (uint32_t)d;   // 32-bit element offset (rows * d < 2^31 checked by the launcher): scalar base + one VGPR offset per access
+        float g[E], xh[E], gm[E];
+        L::load(dy + ro, lane, g);
+        L::load(x + ro, lane, xh);
+        L::load_f32(gs, lane, gm);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            xh[k] = (xh[k] - mu) * rs;
+            ag[k] += g[k] * xh[k];
+            ab[k] += g[k];
+            g[k] *= gm[k];
+            s1 += g[k];
+            s2 += g[k] * xh[k];
+        }
+        const float c1 = wave_sum(s1) * (1.0f / d), c2 = wave_sum(s2) * (1.0f / d);
+        float o[E];
+        if (dres) L::load(dres + ro, lane, o);
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const float v = rs * (g[k] - c1 - xh[k] * c2);
+            o[k] = (float)(bf16_t)(dres ? o[k] + v : v);   // the value as stored (rounded): what dxm and the column sums see
+        }
+        L::store(dx + ro, lane, o);
+        if (EXTRA) {
+            if (thresh) {
+#pragma unroll
+                for (int i = 0; i < L::N16; ++i) {
+                    float mk[8];
+                    dropout_maskN<8>(seed, ro + (uint32_t)((i * 64 + lane) * 8), thresh, inv_keep, mk);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[8 * i + k] = (float)(bf16_t)(o[8 * i + k] * mk[k]);
+                }
+                if constexpr (L::N8 == 1) {
+                    float mk[4];
+                    dropout_maskN<4>(seed, ro + (uint32_t)(512 * L::N16 + 4 * lane), thresh, inv_keep, mk);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[8 * L::N16 + k] = (float)(bf16_t)(o[8 * L::N16 + k] * mk[k]);
+                }
+                L::store(dxm + ro, lane, o);
+            }
+#pragma unroll
+            for (int k = 0; k < E; ++k) ac[k] += o[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int c = L::col(k, lane);
+        red[(w * NP + 0) * d + c] = ag[k];
+        red[(w * NP + 1) * d + c] = ab[k];
+        if (EXTRA) red[(w * NP + 2) * d + c] = ac[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < NP * d; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) s += red[ww * NP * d + c];
+        partial[(int64_t)blockIdx.x * NP * d + c] = s;
+    }
+}
+
 // out[c] = sum_p partial[p][c]  for c < width ; optional split into two outputs (dgamma | dbeta).
 // Block = 64 columns x 4 row-slices (each slice sums every 4th partial row, 4 loads in flight), LDS combine.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partial, int nparts, int width,
@@ -412,6 +574,7 @@ inline int grid_for_rows(int64_t rows) { return (int)std::min<int64_t>((rows + 3
 
 }  // namespace
 
+static bool ln_fit(int d) { const int e = d / 64; return d % 256 == 0 && (e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32); }   // exact lane mapping available
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -481,6 +644,13 @@ int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, v
     if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048) return ECGVIT_EINVAL;
     const int grid = grid_for_rows(rows);
     if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
+    if (dtype == ECGVIT_BF16 && ln_fit(d)) {
+#define LN_FIT(EE) case EE: hipLaunchKernelGGL((layernorm_fwd_fit_kernel<EE>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)x, gamma, beta, (bf16_t *)y, mean, rstd, rows, eps); break;
+        switch (d / 64) { LN_FIT(4) LN_FIT(8) LN_FIT(12) LN_FIT(16) LN_FIT(24) LN_FIT(32) default: return ECGVIT_EINVAL; }
+#undef LN_FIT
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
     const int nv = (d + (dtype == ECGVIT_F32 ? 256 : 512) - 1) / (dtype == ECGVIT_F32 ? 256 : 512);
 #define LN_FWD(T, MV) hipLaunchKernelGGL((layernorm_fwd_kernel<T, MV>), dim3(grid), dim3(256), 0, as_stream(stream), (const T *)x, gamma, beta, (T *)y, mean, rstd, rows, d, eps)
     if (dtype == ECGVIT_F32) { if (nv <= 1) LN_FWD(float, 1); else if (nv <= 2) LN_FWD(float, 2); else if (nv <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
@@ -490,7 +660,7 @@ int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, v
     return ECGVIT_OK;
 }
 
-static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 768); }  // 150 VGPRs -> 3 resident blocks per CU
+static int ln_bwd_grid(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 1024); }  // up to 4 resident blocks per CU (fit kernels); the MAXV kernels hold 3
 
 int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln_bwd_grid(rows) * 3 * d * 4; }
 
@@ -505,6 +675,20 @@ static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, cons
     if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    if (dtype == ECGVIT_BF16 && ln_fit(d) && (int64_t)rows * d < (1ll << 31)) {
+        const size_t ldsf = lds + (size_t)d * 4;   // + gamma
+#define LN_FIT(EE)                                                                                                                \
+    case EE:                                                                                                                      \
+        if (extra) hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, true>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)dxm, seed, th, ik); \
+        else hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, false>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)nullptr, seed, 0u, 1.f); \
+        break;
+        switch (d / 64) { LN_FIT(4) LN_FIT(8) LN_FIT(12) LN_FIT(16) LN_FIT(24) LN_FIT(32) default: return ECGVIT_EINVAL; }
+#undef LN_FIT
+        ECGVIT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((np * d + 63) / 64), dim3(1024), 0, as_stream(stream), (const float *)partial, grid, np * d, dgamma, dbeta, d, extra ? dcolsum : nullptr);
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
     const int nv = (d + (dtype == ECGVIT_F32 ? 256 : 512) - 1) / (dtype == ECGVIT_F32 ? 256 : 512);
 #define LN_BWD(T, MV)                                                                                                             \
     do {                                                                                                                          \

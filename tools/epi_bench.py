@@ -23,6 +23,10 @@ cases = {
  'up bias': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f, epilogue=E.EPI_BIAS, bias=bias),
  'up bias+gelu(+aux)': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f, epilogue=E.EPI_BIAS | E.EPI_GELU, bias=bias, aux=PRE, ldaux=f),
  'up bias+gelu+drop': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_DROPOUT, bias=bias, aux=PRE, ldaux=f, dropout_p=0.1, seed=5),
+ 'up bias+gelu+gradaux+drop (shipped fwd)': lambda: hip.gemm(E.GEMM_NT, X, W1, H, M, f, d, d, d, f, epilogue=E.EPI_BIAS | E.EPI_GELU | E.EPI_GELU_GRAD_AUX | E.EPI_DROPOUT, bias=bias, aux=PRE, ldaux=f, dropout_p=0.1, seed=5),
+ 'dgradT mul_aux+colsum (shipped bwd)': lambda: hip.gemm(E.GEMM_NT, dY, W2t, H, M, f, d, d, d, f, epilogue=E.EPI_MUL_AUX | E.EPI_COLSUM, aux=PRE, ldaux=f, workspace=ws, colsum_out=cs),
+ 'dgradT mul_aux only': lambda: hip.gemm(E.GEMM_NT, dY, W2t, H, M, f, d, d, d, f, epilogue=E.EPI_MUL_AUX, aux=PRE, ldaux=f),
+ 'dgradT colsum only': lambda: hip.gemm(E.GEMM_NT, dY, W2t, H, M, f, d, d, d, f, epilogue=E.EPI_COLSUM, workspace=ws, colsum_out=cs),
  'dgrad plain': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f),
  'dgrad gelu_bwd': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f, epilogue=E.EPI_GELU_BWD, aux=PRE, ldaux=f),
  'dgrad gelu_bwd+drop': lambda: hip.gemm(E.GEMM_NN, dY, W2, H, M, f, d, d, f, f, epilogue=E.EPI_GELU_BWD | E.EPI_DROPOUT, aux=PRE, ldaux=f, dropout_p=0.1, seed=5),
