@@ -102,8 +102,14 @@ template <bool KC> __device__ __forceinline__ bf16x8 frag(const char *tile, int 
         const int colb = (mn_base + (g & 1) * 16 + (i & 3) * 4) * 2;
         const int k = ks * 16 + (g >> 1) * 8 + (i >> 2);  // k and k+4 share (k&3)
         const char *p = tile + k * 512 + (colb ^ ((k & 3) << 6));
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(p + 4 * 512));
+        // Inline asm, not the builtin: with an LDS-DMA in flight hipcc's waitcnt pass cannot prove that the builtin's read does not
+        // alias the DMA's destination and drains vmcnt(0) in front of it -- which serialised every K-tile's prefetch of the k-major
+        // layouts (found in the ISA: `s_waitcnt vmcnt(0)` right after the 8 `buffer_load ... lds` of a phase).  Every caller already
+        // orders these reads by hand (s_waitcnt lgkmcnt(0) + sched_barrier before the consuming MFMAs / the barrier).
+        const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+        bf16x4 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(pa) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(pa) : "memory");
         const u32x2 ul = __builtin_bit_cast(u32x2, lo), uh = __builtin_bit_cast(u32x2, hi);
         u32x4 u;
         u[0] = ul[0]; u[1] = ul[1]; u[2] = uh[0]; u[3] = uh[1];
@@ -391,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[nxt][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks + 1, lane);
                 }
+                if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // asm transposed reads: not tracked by the compiler
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -436,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_v2_kernel(ecgvit_gemm_desc d
 #pragma unroll
                     for (int i = 0; i < 4; ++i) a[nxt][i] = frag<A_KC>(sa, wm * 128 + i * 32, ks + 1, lane);
                 }
+                if constexpr (!A_KC || !B_KC) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // asm transposed reads: not tracked by the compiler
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -1270,6 +1278,114 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_q_kernel(ecgvit_gemm_desc d,
 #undef Q_ADV_B
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient kernel ("TQ": both operands k-major, split-K): the Q kernel's streaming discipline on the k-major images.
+// One (K-slice, tile) item per block; A tiles ([64 k][256 m], 32 KiB) two K-tiles ahead in a 3-slot ring, B tiles one ahead in
+// 2 slots (5 x 32 KiB = all of LDS); a K-tile = four 16-deep phases (12 transposed reads + 2 DMA pieces | 8 MFMAs of 32x32x16),
+// one counted vmcnt(4) per K-tile, waves 4-7 one barrier behind waves 0-3.  The whole-tile schedule it replaces drained
+// vmcnt(0) once per K-tile and wave half (64 KiB in flight at most): both operands of this layout are pure HBM streams.
+template <typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tq_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const int ntile = tiles_m * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else if (sk.splits > 1) {
+        const int gid = xcd_remap(blockIdx.x, ntile * sk.splits);
+        split = gid / ntile;
+        tid = gid - split * ntile;
+    } else {
+        split = 0;
+        tid = xcd_remap(blockIdx.x, ntile);
+    }
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const bf16_t *A = reinterpret_cast<const bf16_t *>(d.A);
+    const bf16_t *B = reinterpret_cast<const bf16_t *>(d.B);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wm == 1;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const FastOp fa = fast_setup<false>(A, d.lda, m0, d.M, kend, wave, lane);
+    const FastOp fb = fast_setup<false>(B, d.ldb, n0, d.N, kend, wave, lane);
+    char *const ringA = smem, *const ringB = smem + 3 * TILE_BYTES;
+    // prologue: A(0), B(0), A(1)
+    fast_dma<false>(fa, d.lda, kbeg, ringA, wave);
+    fast_dma<false>(fb, d.ldb, kbeg, ringB, wave);
+    if (nk > 1) {
+        fast_dma<false>(fa, d.lda, kbeg + BK, ringA + TILE_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    int ga = 0, gb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char *sa = ringA + ga * TILE_BYTES;
+        const char *sb = ringB + gb * TILE_BYTES;
+        char *nA = ringA + (ga == 0 ? 2 : ga - 1) * TILE_BYTES;   // slot of K-tile kt+2
+        char *nB = ringB + (gb ^ 1) * TILE_BYTES;                 // slot of K-tile kt+1
+        const bool b_ok = kt + 1 < nk, a_ok = kt + 2 < nk;
+        const int kB = kbeg + (kt + 1) * BK, kA = kbeg + (kt + 2) * BK;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = frag<false>(sb, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = frag<false>(sa, wm * 128 + i * 32, ks, lane);
+            if (ks == 0) { if (b_ok) fast_dma<false, 0, 2>(fb, d.ldb, kB, nB, wave); }
+            else if (ks == 1) { if (b_ok) fast_dma<false, 2, 4>(fb, d.ldb, kB, nB, wave); }
+            else if (ks == 2) { if (a_ok) fast_dma<false, 0, 2>(fa, d.lda, kA, nA, wave); }
+            else {
+                // the K-tile's one counted wait: everything but A(kt+2) (4 pieces per wave) has landed
+                if (a_ok) { fast_dma<false, 2, 4>(fa, d.lda, kA, nA, wave); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // WAR by construction: the leading group refills this K-tile's B slot in its NEXT phase (phase 0 of kt+1), which runs
+                // while the trailing group is still in this phase's MFMA half -- so this phase's reads retire BEFORE the barrier
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ga = ga == 2 ? 0 : ga + 1;
+        gb ^= 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_store<TO>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
                                                              TO *__restrict__ C, int64_t ldc, EpiParams e) {
@@ -1407,6 +1523,20 @@ int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
         ECGVIT_CHECK_LAUNCH();
         if (d->epilogue & ECGVIT_EPI_COLSUM) {
             hipLaunchKernelGGL(colsum_reduce_kernel, dim3((d->N + 63) / 64), dim3(1024), 0, s, (const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out);
+            ECGVIT_CHECK_LAUNCH();
+        }
+        return ECGVIT_OK;
+    }
+    static const bool tq_ok = [] { const char *e = getenv("ECGVIT_GEMM_TQ"); return !(e && e[0] == '0'); }();
+    if (tq_ok && sched_env < 0 && fast && d->layout == ECGVIT_GEMM_TN && !sk.ablate && sk.k_per_split >= 2 * BK) {
+        if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_bf16_tq_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(gemm_bf16_tq_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        ECGVIT_CHECK_LAUNCH();
+        if (sk.splits > 1) {
+            const int64_t MN = (int64_t)d->M * d->N;
+            const int g = (int)std::min<int64_t>((MN / 4 + 255) / 256, 2048);
+            if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(splitk_reduce2_kernel<bf16_t>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (bf16_t *)d->C, d->ldc, e);
+            else hipLaunchKernelGGL(splitk_reduce2_kernel<float>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (float *)d->C, d->ldc, e);
             ECGVIT_CHECK_LAUNCH();
         }
         return ECGVIT_OK;

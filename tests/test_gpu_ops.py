@@ -735,3 +735,19 @@ def test_attention_bwd_persistent_stream(B, h, N, p):
         o_ref.backward(do.double())
         for i, nm in enumerate('qkv'):
             assert rel_err(new[:, i * d:(i + 1) * d], qr.grad[:, i * d:(i + 1) * d]) < 2e-2, nm
+
+
+def test_gemm_bf16_weight_gradient_stream_is_race_free_and_exact():
+    """the streaming weight-gradient kernel (k-major operands, 3+2 tile rings, counted waits, split-K slabs): small-integer operands
+    make every product and partial sum exact in f32, so dW must EQUAL the integer reference on every repeated launch"""
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K) in ((768, 2304, 40000), (3072, 768, 33333 // 64 * 64 + 17), (256, 256, 130000)):
+        A = torch.randint(-3, 4, (K, M), generator=g).to(BF16).cuda()     # dY: tokens x outputs
+        B = torch.randint(-3, 4, (K, N), generator=g).to(BF16).cuda()     # X:  tokens x inputs
+        ref = A.float().t() @ B.float()                                   # |sum| <= 9 * 130000 < 2^24: exact
+        ws = torch.empty(max(16, hip.gemm_workspace_bytes(hip.GEMM_TN, BF16, M, N, K)), dtype=torch.uint8, device='cuda')
+        C = torch.empty(M, N, device='cuda')
+        for rep in range(10):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_TN, A, B, C, M, N, K, M, N, N, workspace=ws)
+            assert torch.equal(C, ref), (M, N, K, rep, int((C != ref).sum()))
