@@ -1,18 +1,26 @@
-// bf16 MFMA GEMM, large-shape variant: 256x256x64 block tile, 8 waves (2 x 4, wave tile 128 x 64 = 4x2 accumulators of
-// 32x32 -> 128 acc VGPRs), operands streamed HBM -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging, no
-// ds_write), two 64-KiB stages, ONE raw s_barrier per K-tile with the next tile's DMA in flight behind the MFMAs.
+// bf16 MFMA GEMMs for large shapes: 256x256x64 block tile, 8 waves (2 x 4, wave tile 128 x 64 -> 128 accumulator VGPRs), operands
+// streamed HBM -> LDS by LDS-DMA (`buffer_load ... lds`: no VGPR staging, no ds_write).
 //
-// Why this shape (MI355X): per K-tile a wave issues 24 ds_read_b128 (16 A + 8 B fragments) for 32 MFMAs, i.e. 768 LDS
-// cycles per CU against 2048 MFMA cycles per SIMD pair -- the 128^2 register-staged kernel (gemm_bf16.hip) needs 1024 LDS
-// cycles (reads + ds_write staging) per 1024 MFMA cycles and is LDS-bound at ~22 % of peak.
+// Shipped kernels (what `ecgvit_gemm` dispatches to on the train-step shapes):
+//   gemm_bf16_q_kernel   A . B^T (Linear forward; input gradients against the transposed weight shadows): persistent, quadrant-phased,
+//                        v_mfma_f32_16x16x32_bf16, half-tile operand stream continuous across output tiles (A 3-deep, B 2-deep)
+//   gemm_bf16_tq_kernel  A^T . B (weight gradients, split-K): the same streaming discipline on k-major images, 32x32x16 MFMA
+// Kept as A/B partners, for the A . B layout and for ragged shapes: gemm_bf16_v2_kernel<SCHED> (0 lockstep, 1 ping-pong 16-deep,
+// 3 asymmetric ring, 4 ablation only, 5 whole-tile ping-pong), gemm_bf16_ring_kernel, gemm_bf16_pers_kernel.
+//
+// Why this tile (MI355X): per K-tile a wave issues 24 ds_read_b128 for 64 MFMA-16x16x32 (or 32 MFMA-32x32x16), i.e. 768 LDS cycles
+// per CU against 2048 MFMA cycles per SIMD pair -- the 128^2 register-staged kernel (gemm_bf16.hip) needs 1024 LDS cycles (reads +
+// ds_write staging) per 1024 MFMA cycles and is LDS-bound at ~22 % of peak.  What bounds THIS tile is measured in DESIGN.md 4.
 //
 // LDS images (the DMA destination is wave-uniform base + lane*16, so swizzles are applied to the per-lane SOURCE address):
-//   K-contiguous operand  [256 rows][64 k]   (128-B rows): 16-B chunk ^= (row>>1)&7        -> conflict-free ds_read_b128
+//   K-contiguous operand  [rows][64 k]       (128-B rows): 16-B chunk ^= (row>>1)&7        -> conflict-free ds_read_b128 for both the
+//                                            32x32x16 (row = lane&31) and the 16x16x32 (row = lane&15, chunk = 4s + lane>>4) fragments
 //   k-major operand       [64 k][256 mn]     (512-B rows): 16-B chunk ^= (k&3)<<2          -> the 4 k-rows of one
 //                         ds_read_b64_tr_b16 half-wave land on the 4 distinct 64-B quarters of the bank row
-// Out-of-range source chunks (M/N tails of k-major operands, K tails) are pointed at a 16-B zero word in device memory.
-// Epilogue: each wave drains its accumulators through a private 64 x 68 f32 LDS patch (two passes) and writes 128-B row
-// segments with bias / GELU / GELU' / dropout / residual applied in f32 (same semantics as gemm_bf16.hip).
+// Out-of-range rows fall beyond the buffer descriptor's num_records and read as zero (fast path) or are pointed at a zero word.
+// Transposed reads are issued as inline asm: with an LDS-DMA in flight hipcc's waitcnt pass drains vmcnt(0) in front of the builtin.
+// Epilogue: accumulators -> per-wave LDS patch -> 128-B row segments with bias / GELU / GELU' / dropout / residual / x-aux / column
+// sums applied in f32 (same semantics as gemm_bf16.hip).
 #include "common.cuh"
 #include <cstdlib>
 
