@@ -564,3 +564,26 @@ def test_device_feeder_pinned_async_batches_and_fused_transform(tmp_path):
         o_raw = m_raw(sample_values=b['sample_values'], labels=b['labels'])
         o_ref = m_ref(sample_values=torch.from_numpy(host).cuda(), labels=b['labels'])
     assert max_err(o_raw.logits, o_ref.logits.cpu()) < 1e-4 and abs(float(o_raw.loss) - float(o_ref.loss)) < 1e-5
+
+
+def test_training_overfits_one_batch_on_the_large_shape_kernels():
+    """end-to-end: 40 fused steps on ONE fixed batch at a geometry that runs every large-shape kernel (persistent A.B^T GEMM for forward
+    and input gradients, streaming weight-gradient GEMM, persistent attention backward with N = 251 > 128, exact-fit LayerNorm,
+    dropout 0.1): the bf16 path must drive the loss down like the f32 parity path does"""
+    kw = dict(max_signal_length=5000, patch_size=20, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+              hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    x, y = O.synthetic_batch(16, length=5000, seed=3)
+    curves = {}
+    for dtype in (BF16, F32):
+        torch.manual_seed(11)
+        m = E.EcgVit(config=E.EcgVitConfig(**kw), compute_dtype=dtype).cuda().train()
+        ts = E.HipTrainStep(m, dict(n_step=40, learning_rate=1e-3, schedule='constant'), sync_nonfinite=True)
+        torch.manual_seed(5)                                   # same dropout seeds for both paths
+        losses = [float(ts.step(x.cuda(), y.cuda())[0]) for _ in range(40)]
+        ts.finish()
+        assert all(np.isfinite(losses))
+        curves[dtype] = losses
+    b, f = curves[BF16], curves[F32]
+    assert f[-1] < 0.5 * f[0] and b[-1] < 0.5 * b[0], (b[0], b[-1], f[0], f[-1])          # it learns
+    assert abs(b[0] - f[0]) / f[0] < 2e-2
+    assert abs(np.mean(b[-5:]) - np.mean(f[-5:])) < 0.05 * max(1.0, f[0]), (b[-5:], f[-5:])   # same trajectory within bf16 / mask noise
