@@ -93,7 +93,7 @@ def pmc_traffic(kernel_key, args):
     measured on this same command line; null when the run differs from the profiled workload."""
     if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512) or args.objective != 'supervised':
         return None
-    path = os.path.join(ROOT, 'profiles', 'r01_e_pmc_traffic_base_b512.json')
+    path = os.path.join(ROOT, 'profiles', 'r01_f_pmc_traffic_base_b512.json')
     try:
         with open(path) as f:
             return json.load(f)[kernel_key]['hbm_bytes_per_launch']
