@@ -17,9 +17,12 @@ for f in sorted(glob.glob('$O/*/*/*counter_collection.csv')):
         elif 'gemm_bf16_pers_kernel<true, true' in n: k = 'gemm_nt'
         elif 'gemm_bf16_v2_kernel<true, true' in n: k = 'gemm_nt_patch'     # patch-embed (K = 240: generic DMA path)
         elif 'gemm_bf16_v2_kernel<true, false' in n: k = 'gemm_nn'
+        elif 'gemm_bf16_tq_kernel' in n: k = 'gemm_tq'                        # streaming weight-gradient GEMM
         elif 'gemm_bf16_v2_kernel<false, false' in n: k = 'gemm_tn'
         elif 'attn_fwd' in n: k = 'attn_fwd'
         elif 'attn_bwd' in n: k = 'attn_bwd'
+        elif 'layernorm_bwd_fit' in n: k = 'ln_bwd'
+        elif 'layernorm_fwd_fit' in n: k = 'ln_fwd'
         elif 'layernorm_bwd' in n: k = 'ln_bwd'
         elif 'layernorm_fwd' in n: k = 'ln_fwd'
         else: continue
