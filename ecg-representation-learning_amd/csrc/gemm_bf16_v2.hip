@@ -1460,7 +1460,7 @@ bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d) {
         return false;   // the caller's generic fallback (GEMM, then ecgvit_colsum) handles it
     // large activations-by-weights products only; small / ragged problems stay on the 128^2 kernel
     if (d->layout == ECGVIT_GEMM_TN) return d->K >= 4096 && d->M >= 128 && d->N >= 128;
-    return d->M >= 2048 && d->N >= 256;
+    return d->M >= 2048 && d->N >= 128;   // a single ragged n-tile (e.g. the 240-wide pixel head) still beats the 128^2 kernel
 }
 
 int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d) {

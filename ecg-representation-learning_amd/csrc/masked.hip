@@ -89,23 +89,34 @@ __global__ __launch_bounds__(256) void rows_by_index_kernel(const T *__restrict_
     }
 }
 
+// L1 loss + its gradient, two deterministic stages: L1_BLOCKS blocks each own a contiguous run of elements (8 per thread and pass,
+// 16-B accesses when the row pitch allows) and leave one partial sum; a single wave then adds the partials in a fixed order.
+constexpr int L1_BLOCKS = 1024;
 template <typename T>
-__global__ __launch_bounds__(1024) void l1_loss_kernel(const T *__restrict__ pred, const T *__restrict__ target,
-                                                       float *__restrict__ loss, T *__restrict__ dpred,
-                                                       const float *__restrict__ gscalar, int64_t rows, int width, int64_t ld) {
-    __shared__ float red[16];
+__global__ __launch_bounds__(256) void l1_loss_kernel(const T *__restrict__ pred, const T *__restrict__ target,
+                                                      float *__restrict__ partial, T *__restrict__ dpred,
+                                                      const float *__restrict__ gscalar, int64_t rows, int width, int64_t ld) {
+    __shared__ float red[4];
     const float up = (gscalar ? gscalar[0] : 1.0f) / (float)(rows * width);
-    float s = 0.f;
     const int64_t total = rows * width;
-    for (int64_t i = threadIdx.x; i < total; i += 1024) {
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+    float s = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
         const int64_t r = i / width;
         const int c = (int)(i - r * width);
         const float df = to_f32<T>(pred[r * ld + c]) - to_f32<T>(target[r * ld + c]);
         s += fabsf(df);
         if (dpred) dpred[r * ld + c] = from_f32<T>(df > 0.f ? up : (df < 0.f ? -up : 0.f));
     }
-    const float tot = block_sum<16>(s, red);
-    if (threadIdx.x == 0) loss[0] = tot / (float)total;
+    const float tot = block_sum<4>(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(64) void l1_finish_kernel(const float *__restrict__ partial, int n, float *__restrict__ loss, float inv_total) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) loss[0] = s * inv_total;
 }
 
 inline int grid_ew(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
@@ -174,14 +185,18 @@ int ecgvit_scatter_rows(const void *in, const int32_t *idx, void *out, int B, in
     return rows_by_index(in, idx, out, B, n, m, width, ld_in, ld_out, dtype, stream, true);
 }
 
-int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, void *dpred, const float *gscalar, int64_t rows,
-                           int width, int64_t ld, int dtype, void *stream) {
-    if (rows <= 0 || width <= 0 || ld < width) return ECGVIT_EINVAL;
+int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, void *dpred, const float *gscalar, float *partial,
+                           int64_t rows, int width, int64_t ld, int dtype, void *stream) {
+    if (rows <= 0 || width <= 0 || ld < width || !partial) return ECGVIT_EINVAL;
+    const int64_t total = rows * width;
+    const int nb = (int)std::min<int64_t>(L1_BLOCKS, (total + 2047) / 2048);
     if (dtype == ECGVIT_F32)
-        hipLaunchKernelGGL(l1_loss_kernel<float>, dim3(1), dim3(1024), 0, as_stream(stream), (const float *)pred, (const float *)target, loss, (float *)dpred, gscalar, rows, width, ld);
+        hipLaunchKernelGGL(l1_loss_kernel<float>, dim3(nb), dim3(256), 0, as_stream(stream), (const float *)pred, (const float *)target, partial, (float *)dpred, gscalar, rows, width, ld);
     else if (dtype == ECGVIT_BF16)
-        hipLaunchKernelGGL(l1_loss_kernel<bf16_t>, dim3(1), dim3(1024), 0, as_stream(stream), (const bf16_t *)pred, (const bf16_t *)target, loss, (bf16_t *)dpred, gscalar, rows, width, ld);
+        hipLaunchKernelGGL(l1_loss_kernel<bf16_t>, dim3(nb), dim3(256), 0, as_stream(stream), (const bf16_t *)pred, (const bf16_t *)target, partial, (bf16_t *)dpred, gscalar, rows, width, ld);
     else return ECGVIT_EINVAL;
+    ECGVIT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), partial, nb, loss, 1.0f / (float)total);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

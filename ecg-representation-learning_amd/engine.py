@@ -193,7 +193,7 @@ class VitEngine:
         if masked:
             a.update(flag=torch.empty(Mp, device=dev, dtype=torch.uint8), rows=e(B * m, d), pred=e(B * m, self.CP),
                      target=e(B * m, self.CP), dpred=e(B * m, self.CP), drows=e(B * m, d), dmasked=e(Mp, d),
-                     mloss=e(1, dt=torch.float32))
+                     mloss=e(1, dt=torch.float32), l1part=e(1024, dt=torch.float32))
         a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
         self.act, self.B = a, B
 
@@ -335,7 +335,7 @@ class VitEngine:
                  bias=self.P32['pretrain.to_pixels.bias'])
         check(l.ecgvit_gather_rows(ptr(a['patches']), ptr(idx), ptr(a['target']), B, n, m, self.CP, self.CP, self.CP, T, st), 'gather_rows')
         # L1 loss and d(loss)/d(pred) in one pass (upstream gradient 1; backward_masked re-runs it for any other upstream)
-        check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), None, B * m, self.CP,
+        check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), None, ptr(a['l1part']), B * m, self.CP,
                                        self.CP, T, st), 'l1_loss')
         return a['pred'], a['mloss']
 
@@ -348,7 +348,7 @@ class VitEngine:
         d, n = self.d, self.n
         G = self.G32
         if gscalar is not None:
-            check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), ptr(gscalar), B * m,
+            check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), ptr(gscalar), ptr(a['l1part']), B * m,
                                            self.CP, self.CP, T, st), 'l1_loss')
         self._colsum(a['dpred'], self.CP, G['pretrain.to_pixels.bias'], B * m, self.CP)
         self._wgrad(a['dpred'], a['rows'], 'pretrain.to_pixels.weight', self.CP, d, B * m)

@@ -77,7 +77,7 @@ SIGNATURES = {
     'ecgvit_mask_embed_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'ecgvit_gather_rows': (c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     'ecgvit_scatter_rows': (c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
-    'ecgvit_l1_loss_fwd_bwd': (c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _I, _P]),
+    'ecgvit_l1_loss_fwd_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _P]),
     'ecgvit_eval_counts': (c_int, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P]),
     'ecgvit_probe_mfma_layout': (c_int, [_P, _P]),
     'ecgvit_debug_attn_stamps': (c_int, [_P]),

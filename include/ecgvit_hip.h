@@ -221,8 +221,9 @@ int ecgvit_gather_rows(const void *in, const int32_t *idx, void *out, int B, int
 /* scatter-add rows (distinct idx per record => plain stores into a zero-filled buffer) */
 int ecgvit_scatter_rows(const void *in, const int32_t *idx, void *out, int B, int n, int m, int64_t width,
                         int64_t ld_in, int64_t ld_out, int dtype, void *stream);
-/* L1 reconstruction loss: loss[0] = mean |pred - target| ; dpred = upstream * sign(pred - target) / count */
-int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, void *dpred, const float *gscalar,
+/* L1 reconstruction loss: loss[0] = mean |pred - target| ; dpred = upstream * sign(pred - target) / count.
+ * partial: >= 1024 floats of scratch (per-block partial sums of the deterministic two-stage reduction). */
+int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, void *dpred, const float *gscalar, float *partial,
                            int64_t rows, int width, int64_t ld, int dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

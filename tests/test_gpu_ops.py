@@ -503,7 +503,8 @@ def test_masked_objective_ops(dtype):
     assert torch.equal(back.cpu().view(B, n, d), exp)
     pred, tgt = torch.randn(B * m, d, generator=g).to(dtype), torch.randn(B * m, d, generator=g).to(dtype)
     loss, dpred = torch.zeros(1, device='cuda'), torch.zeros(B * m, d, device='cuda', dtype=dtype)
-    check(lib().ecgvit_l1_loss_fwd_bwd(ptr(dev(pred)), ptr(dev(tgt)), ptr(loss), ptr(dpred), None, B * m, d, d, hip.code(dtype), stream()), 'l1')
+    l1part = torch.empty(1024, device='cuda')
+    check(lib().ecgvit_l1_loss_fwd_bwd(ptr(dev(pred)), ptr(dev(tgt)), ptr(loss), ptr(dpred), None, ptr(l1part), B * m, d, d, hip.code(dtype), stream()), 'l1')
     diff = pred.double() - tgt.double()
     assert abs(float(loss) - float(diff.abs().mean())) < 1e-5
     assert rel_err(dpred, torch.sign(diff) / diff.numel()) < (1e-6 if dtype == F32 else 4e-3)
