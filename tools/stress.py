@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""race / exactness stress of the streaming kernels (counted vmcnt schedules): random shapes, small-integer operands (exact f32 sums),
+repeated launches, persistent attention backward vs the one-item kernel.  python tools/stress.py [seconds]"""
+import os, sys, time, random
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ecg_representation_learning_amd import hip
+from ecg_representation_learning_amd.hip import lib, check, ptr, stream
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = random.Random(1234)
+bf = torch.bfloat16
+t_end = time.time() + budget
+n_nt = n_tn = n_at = bad = 0
+while time.time() < t_end:
+    kind = rng.choice(['nt', 'nt', 'tn', 'attn'])
+    if kind == 'nt':
+        M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
+        N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
+        K = 64 * rng.randrange(3, 50)
+        A = torch.randint(-3, 4, (M, K), device='cuda').to(bf); B = torch.randint(-3, 4, (N, K), device='cuda').to(bf)
+        ref = A.float() @ B.float().t()
+        out_f32 = rng.random() < 0.3
+        C = torch.empty(M, N, device='cuda', dtype=torch.float32 if out_f32 else bf)
+        want = ref if out_f32 else ref.to(bf)
+        for _ in range(4):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N)
+            if not torch.equal(C, want):
+                bad += 1; print('NT MISMATCH', M, N, K, out_f32, int((C != want).sum()), flush=True)
+        n_nt += 1
+    elif kind == 'tn':
+        M = 256 * rng.randrange(1, 13); N = 256 * rng.randrange(1, 13)
+        K = rng.randrange(4096, 140000)
+        A = torch.randint(-2, 3, (K, M), device='cuda').to(bf); B = torch.randint(-2, 3, (K, N), device='cuda').to(bf)
+        ref = A.float().t() @ B.float()
+        ws = torch.empty(max(16, hip.gemm_workspace_bytes(hip.GEMM_TN, bf, M, N, K)), dtype=torch.uint8, device='cuda')
+        C = torch.empty(M, N, device='cuda')
+        for _ in range(3):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_TN, A, B, C, M, N, K, M, N, N, workspace=ws)
+            if not torch.equal(C, ref):
+                bad += 1; print('TN MISMATCH', M, N, K, int((C != ref).sum()), flush=True)
+        n_tn += 1
+    else:
+        h = rng.choice([1, 2, 3, 5, 12]); N = rng.randrange(129, 257); B = rng.choice([3, 40, 90, 300]) if h < 12 else rng.choice([8, 30, 64])
+        p = rng.choice([0.0, 0.1, 0.3]); d = h * 64
+        qkv = (torch.randn(B * N, 3 * d, device='cuda') * 1.2).to(bf); do = torch.randn(B * N, d, device='cuda').to(bf)
+        out = torch.empty(B * N, d, device='cuda', dtype=bf); lse = torch.zeros(B * h * N, device='cuda')
+        check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'f')
+        res = []
+        for pers in ('1', '1', '1', '0'):
+            os.environ['ECGVIT_ATTN_PERSIST'] = pers
+            r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=bf)
+            check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
+            torch.cuda.synchronize(); res.append(r)
+        os.environ.pop('ECGVIT_ATTN_PERSIST', None)
+        if not (torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])):
+            bad += 1; print('ATTN NONDETERMINISTIC', B, h, N, p, flush=True)
+        err = float((res[0].float() - res[3].float()).norm() / res[3].float().norm())
+        if not (err < 3e-3) or not torch.isfinite(res[0].float()).all():
+            bad += 1; print('ATTN MISMATCH vs one-item kernel', B, h, N, p, err, flush=True)
+        n_at += 1
+print(f'stress done: {n_nt} A.B^T shapes, {n_tn} A^T.B shapes, {n_at} attention cases, {bad} failures', flush=True)
+sys.exit(1 if bad else 0)
