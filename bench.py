@@ -36,6 +36,7 @@ CONFIGS = {
     'base': ('ecg-vit-base', 512),
     'small': ('ecg-vit-small', 256),
     'tiny': ('ecg-vit-tiny', 256),
+    'large': ('ecg-vit-large', 256),
     'tiny2': (dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512), 32),
 }
 
