@@ -1445,7 +1445,10 @@ inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
     const int ksteps = (d->K + BK - 1) / BK;
     // one block per CU: fill ONE round of the 256 CUs (never 2.1 rounds); a multiple of 8 slices lets each XCD own whole K-slices
     int s = 256 / ntile;
-    if (s >= 8) s &= ~7;
+    // a multiple of 8 slices lets each XCD own whole K-slices (best L2 locality), but only if the rounding leaves < 7 % of the CUs idle:
+    // 27 tiles x 8 slices = 216 blocks wastes 16 % of the chip for the whole launch, 27 x 9 = 243 (XCD-contiguous order) does not
+    static const bool round8 = [] { const char *e = getenv("ECGVIT_GEMM_SPLITROUND"); return e && e[0] == '1'; }();   // 1 = always round (A/B)
+    if (s >= 8 && (round8 || (s & ~7) * ntile * 100 >= s * ntile * 93)) s &= ~7;
     if (s < 1) s = 1;
     s = std::min(s, std::max(1, ksteps / 16));   // keep >= 16 K-steps per slice
     return std::max(1, std::min(s, 64));
