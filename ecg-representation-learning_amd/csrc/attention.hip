@@ -476,15 +476,17 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
 
-template <bool DROP>
+// Records longer than 256 tokens (N <= 512, e.g. patch 10 -> 501) run as TWO launches, one per half of the keys: `k0` is the first key
+// of this launch's 256-key window, queries always run over all of N; the second launch adds its dQ to the first one's (ACCUM).
+template <bool DROP, bool ACCUM>
 __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                             const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                             bf16_t *__restrict__ dqkv, int N, int h, float scale, uint64_t seed,
-                                                            uint32_t thresh, float inv_keep, int nitems) {
-    constexpr int NKT = 8, NK = 256, IMG = 32768, DSB = 16384, SLAB = 12288;
-    __shared__ __attribute__((aligned(1024))) char smem[2 * IMG + 4 * SLAB + 2 * DSB + 2 * NK * 4 + 2 * 32 * 4];
+                                                            uint32_t thresh, float inv_keep, int nitems, int k0) {
+    constexpr int NKT = 8, NK = 256, NQ = 512, IMG = 32768, DSB = 16384, SLAB = 12288;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * IMG + 4 * SLAB + 2 * DSB + 2 * NQ * 4 + 2 * 32 * 4];
     char *const Kimg0 = smem, *const slab0 = smem + 2 * IMG, *const dSimg = slab0 + 4 * SLAB;
-    float *const lse_s = reinterpret_cast<float *>(dSimg + 2 * DSB), *const delta_s = lse_s + 2 * NK;
+    float *const lse_s = reinterpret_cast<float *>(dSimg + 2 * DSB), *const delta_s = lse_s + 2 * NQ;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -515,6 +517,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         vo_k[i] = row * d3 * 2 + (((lane & 7) ^ swz3(row)) * 16);
     }
     const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_d = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
+    const uint32_t bytes_k = (uint32_t)(((int64_t)(N - k0 - 1) * d3 + 64) * 2);   // K / V / dK / dV rows of this launch's key window (keys >= N: out of bounds)
 
     struct Item { const bf16_t *q, *o, *dO; int bh, b, hd; };
     auto make_item = [&](int it) {
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         }
     };
     auto dma_k = [&](const Item &x, char *img) {
-        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + d), 0, bytes_q, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + d + (int64_t)k0 * d3), 0, bytes_k, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, vo_k[i], 0, 0, 0);
     };
@@ -547,14 +550,14 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     // the hardware): no lane predicate, so each wave issues the same number of memory instructions whatever N is -- the counted
     // waits in the loop depend on it.
     auto load_v = [&](const Item &x, bf16x8 (&v)[4]) {
-        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + 2 * d), 0, bytes_q, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + 2 * d + (int64_t)k0 * d3), 0, bytes_k, 0x00020000);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
             v[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rv, (mykey * d3 + ks * 16 + 8 * lh) * 2, 0, 0));
     };
     auto load_lse = [&](const Item &x) {
         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)(lse + (int64_t)x.bh * N), 0, (uint32_t)N * 4u, 0x00020000);
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)(threadIdx.x & 255) * 4, 0, 0));   // scaled by log2(e) when stored
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (int)threadIdx.x * 4, 0, 0));   // scaled by log2(e) when stored
     };
     // delta of the slab in ring slot `slot` -> delta_s[buf][32]: wave w owns rows 4w..4w+3, 16 lanes per row, 4 elements per lane
     auto slab_delta = [&](int slot, int buf) {
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         dma_slab(cur, 0, 0);
         dma_slab(cur, 1, 1);
         dma_slab(cur, 2, 2);
-        if (threadIdx.x < 256) lse_s[threadIdx.x] = l0 * 1.44269504088896340736f;
+        lse_s[threadIdx.x] = l0 * 1.44269504088896340736f;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         const bool has_next = next_it < nitems;
         if (has_next) nxt = make_item(next_it);
         const char *Kimg = Kimg0 + par * IMG;
-        const float *lse_c = lse_s + par * NK;
+        const float *lse_c = lse_s + par * NQ;
         f32x16 dKt[2], dVt[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             const char *Qrow = slab0 + slot * SLAB, *dOrow = Qrow + 4096;
             const float *delta_c = delta_s + (jj & 1) * 32;
             const uint32_t hstep = (uint32_t)((N + 1) >> 1) * ECGVIT_WEYL;
-            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)(mykey >> 1)) * ECGVIT_WEYL;
+            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)((mykey + k0) >> 1)) * ECGVIT_WEYL;
             const uint32_t podd = (uint32_t)(lane & 1);
             f32x16 s, dp;
 #pragma unroll
@@ -748,6 +751,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
                 const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
+                if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16)
+                    const bf16x4 o = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
+                }
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
             }
             slot = (slot + 1) & 3;
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                     const int row = i * 8 + (lane >> 3), ch = lane & 7;
                     const int key = wave * 32 + row;
                     const u32x4 val = *reinterpret_cast<const u32x4 *>(patch + img_off(row, ch * 16));
-                    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + (1 + which) * d + cur.hd * 64), 0, bytes_q, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + ((int64_t)cur.b * N + k0) * d3 + (1 + which) * d + cur.hd * 64), 0, bytes_k, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(val, rkv, (key * d3 + ch * 8) * 2, 0, 0);   // keys >= N: dropped
                 }
             }
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         // ---- switch to the next item: its K image and LSE row were fetched during query block 1, its V fragments during the drain
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) vf[ks] = vfn[ks];
-        if (threadIdx.x < 256) lse_s[(par ^ 1) * NK + threadIdx.x] = lse_n * 1.44269504088896340736f;
+        lse_s[(par ^ 1) * NQ + threadIdx.x] = lse_n * 1.44269504088896340736f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // patches drained (the next dS write may reuse them); LSE row visible
         par ^= 1;
@@ -899,7 +907,7 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
 
 int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
                          int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
-    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 256 || B < 1 || h < 1) return ECGVIT_EINVAL;
+    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) % 16) return ECGVIT_EINVAL;
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
@@ -910,11 +918,17 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     if (pers && N > 128 && !ablate && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31)) {
         const int nitems = B * h;
         const dim3 pg((unsigned)(nitems < 256 ? nitems : 256));
-        if (th) hipLaunchKernelGGL(attn_bwd_pers_kernel<true>, pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems);
-        else hipLaunchKernelGGL(attn_bwd_pers_kernel<false>, pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems);
+#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0)
+        if (th) PERS(true, false, 0); else PERS(false, false, 0);
         ECGVIT_CHECK_LAUNCH();
+        if (N > 256) {   // second window of keys; its dQ accumulates on the first launch's (stream order)
+            if (th) PERS(true, true, 256); else PERS(false, true, 256);
+            ECGVIT_CHECK_LAUNCH();
+        }
+#undef PERS
         return ECGVIT_OK;
     }
+    if (N > 256) return ECGVIT_EINVAL;   // the one-item kernels hold all keys of a record-head on 8 waves
 #define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, ablate)
     if (N <= 128) { if (th) BWD(4, true); else BWD(4, false); }
     else { if (th) BWD(8, true); else BWD(8, false); }

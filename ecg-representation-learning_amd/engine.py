@@ -26,6 +26,9 @@ def _align(n, a=8):
 
 
 _DGRAD_T = os.environ.get('ECGVIT_DGRAD_T', '1') != '0'   # experiments: 0 = input gradients on the A.B kernel
+# 256 < N <= 512 tokens: the fused persistent backward runs as two key windows; 1 = the exact-f32 recompute fallback instead (A/B, and the
+# only way when ECGVIT_ATTN_PERSIST=0)
+_LONG_FALLBACK = os.environ.get('ECGVIT_ATTN_LONG_FALLBACK', '0') == '1' or os.environ.get('ECGVIT_ATTN_PERSIST', '1') == '0'
 
 
 class ParamLayout:
@@ -185,9 +188,9 @@ class VitEngine:
                  dxm=e(M, d))
         if T == torch.float32:
             a.update(pd=e(B * h * N * N), dp=e(B * h * N * N))
-        elif N > 256:
-            # long records (seq = 500 patches): the fused attention BACKWARD holds one record-head's keys on 8 waves (N <= 256); beyond
-            # that the backward recomputes the probabilities with the exact-f32 batched kernels of the parity path on f32 copies
+        elif N > 256 and _LONG_FALLBACK:
+            # long records (seq = 500 patches), fallback only: the backward recomputes the probabilities with the exact-f32 batched
+            # kernels of the parity path on f32 copies (the shipped path runs the fused persistent backward as two 256-key windows)
             NP = (N + 1) & ~1   # row pitch of the fused kernel's dropout index
             f32 = torch.float32
             a.update(lq=e(M, 3 * d, dt=f32), ldo=e(M, d, dt=f32), ldq=e(M, 3 * d, dt=f32), lp=e(B * h * N * NP, dt=f32),
@@ -489,7 +492,7 @@ class VitEngine:
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
             self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d)
-            if self.dtype == torch.bfloat16 and N > 256:
+            if self.dtype == torch.bfloat16 and N > 256 and _LONG_FALLBACK:
                 self._attn_bwd_long(L, B, ph, s0 + 1)
             elif self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,

@@ -346,7 +346,7 @@ def _attn_ref(qkv, B, N, h, dh, scale, mask=None):
     return o, lse, p
 
 
-@pytest.mark.parametrize('N', [51, 251, 128, 256, 1, 33])
+@pytest.mark.parametrize('N', [51, 251, 128, 256, 1, 33, 257, 300, 501, 512])
 def test_attention_bf16_fwd_bwd(N):
     g = torch.Generator().manual_seed(N)
     B, h, dh = 2, 3, 64
@@ -698,7 +698,8 @@ def test_dropout_mask_statistics():
     assert abs(float((z0 * z1).mean()) / float((z0 * z0).mean())) < 4e-3   # seeds 1 and 2: unrelated masks
 
 
-@pytest.mark.parametrize('B,h,N,p', [(24, 12, 251, 0.0), (45, 6, 200, 0.0), (64, 5, 130, 0.0), (40, 12, 251, 0.2), (90, 3, 256, 0.1)])
+@pytest.mark.parametrize('B,h,N,p', [(24, 12, 251, 0.0), (45, 6, 200, 0.0), (64, 5, 130, 0.0), (40, 12, 251, 0.2), (90, 3, 256, 0.1),
+                                     (30, 10, 501, 0.0), (70, 4, 384, 0.0)])
 def test_attention_bwd_persistent_stream(B, h, N, p):
     """the persistent backward (slab stream continuous across (record, head) items, counted waits, 1-3 items per workgroup) against
     the double-precision reference (p = 0) and against the one-item-per-workgroup kernel on the same dropout mask (p > 0);
@@ -726,8 +727,9 @@ def test_attention_bwd_persistent_stream(B, h, N, p):
         assert torch.isfinite(new.float()).all()
         for _ in range(5):
             assert torch.equal(bwd(True), new)
-        old = bwd(False)
-        assert rel_err(new, old.float().double().cpu()) < 2e-3
+        if N <= 256:                                             # the one-item kernel holds at most 256 keys
+            old = bwd(False)
+            assert rel_err(new, old.float().double().cpu()) < 2e-3
     finally:
         os.environ.pop('ECGVIT_ATTN_PERSIST', None)
     if p == 0.0:
