@@ -42,13 +42,13 @@ while time.time() < t_end:
                 bad += 1; print('TN MISMATCH', M, N, K, int((C != ref).sum()), flush=True)
         n_tn += 1
     else:
-        h = rng.choice([1, 2, 3, 5, 12]); N = rng.randrange(129, 257); B = rng.choice([3, 40, 90, 300]) if h < 12 else rng.choice([8, 30, 64])
+        h = rng.choice([1, 2, 3, 5, 12]); N = rng.randrange(129, 513); B = rng.choice([3, 40, 90, 300]) if h < 12 else rng.choice([8, 30, 64])
         p = rng.choice([0.0, 0.1, 0.3]); d = h * 64
         qkv = (torch.randn(B * N, 3 * d, device='cuda') * 1.2).to(bf); do = torch.randn(B * N, d, device='cuda').to(bf)
         out = torch.empty(B * N, d, device='cuda', dtype=bf); lse = torch.zeros(B * h * N, device='cuda')
         check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'f')
         res = []
-        for pers in ('1', '1', '1', '0'):
+        for pers in ('1', '1', '1', '0' if N <= 256 else '1'):   # the one-item kernel covers N <= 256 only
             os.environ['ECGVIT_ATTN_PERSIST'] = pers
             r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=bf)
             check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
