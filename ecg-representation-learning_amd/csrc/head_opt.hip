@@ -78,23 +78,33 @@ __global__ __launch_bounds__(256) void bce_bwd_kernel(const float *__restrict__ 
 // stage 1 (grid = K blocks) leaves T in the dW buffer; stage 2 (one thread per column) finishes all four.
 __global__ __launch_bounds__(256) void head_bwd_t_kernel(const float *__restrict__ dl, const float *__restrict__ xhat,
                                                          float *__restrict__ T, float *__restrict__ dbias, int B, int d, int K) {
-    const int k = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += 256) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int b = 0;
-        for (; b + 3 < B; b += 4) {
+    // block = (class k, group of 64 columns); 64 columns x 4 batch slices, fixed-order LDS combine (deterministic).
+    // (one block per class with a 512-deep sequential loop per thread took 159 us for 28 MFLOP)
+    __shared__ float red[4][64];
+    __shared__ float redb[4][64];
+    const int groups = (d + 63) / 64;
+    const int k = blockIdx.x / groups, c = (blockIdx.x - k * groups) * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f, sb = 0.f;
+    if (c < d) {
+        int b = sl;
+        for (; b + 4 < B; b += 8) {
             a0 += dl[(int64_t)b * K + k] * xhat[(int64_t)b * d + c];
-            a1 += dl[(int64_t)(b + 1) * K + k] * xhat[(int64_t)(b + 1) * d + c];
-            a2 += dl[(int64_t)(b + 2) * K + k] * xhat[(int64_t)(b + 2) * d + c];
-            a3 += dl[(int64_t)(b + 3) * K + k] * xhat[(int64_t)(b + 3) * d + c];
+            a1 += dl[(int64_t)(b + 4) * K + k] * xhat[(int64_t)(b + 4) * d + c];
         }
-        for (; b < B; ++b) a0 += dl[(int64_t)b * K + k] * xhat[(int64_t)b * d + c];
-        T[(int64_t)k * d + c] = (a0 + a1) + (a2 + a3);
+        for (; b < B; b += 4) a0 += dl[(int64_t)b * K + k] * xhat[(int64_t)b * d + c];
     }
-    if (threadIdx.x == 0) {
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dl[(int64_t)b * K + k];
-        dbias[k] = acc;
+    if (blockIdx.x == k * groups)   // the class's first column group also sums its logit gradients: thread t takes rows t, t+256, ...
+        for (int b = threadIdx.x; b < B; b += 256) sb += dl[(int64_t)b * K + k];
+    red[sl][threadIdx.x & 63] = a0 + a1;
+    redb[sl][threadIdx.x & 63] = sb;
+    __syncthreads();
+    if (sl == 0) {
+        if (c < d) T[(int64_t)k * d + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (blockIdx.x == k * groups) {
+            float t = (redb[0][threadIdx.x] + redb[1][threadIdx.x]) + (redb[2][threadIdx.x] + redb[3][threadIdx.x]);
+            t = wave_sum(t);
+            if (threadIdx.x == 0) dbias[k] = t;
+        }
     }
 }
 
@@ -306,7 +316,7 @@ int ecgvit_head_bwd(const float *dlogits, const float *xhat, const float *rstd, 
     hipStream_t s = as_stream(stream);
     const size_t esz = dtype == ECGVIT_F32 ? 4 : 2;
     if (hipMemsetAsync(dX, 0, (size_t)B * N * d * esz, s) != hipSuccess) return ECGVIT_ELAUNCH;
-    hipLaunchKernelGGL(head_bwd_t_kernel, dim3(K), dim3(256), 0, s, dlogits, xhat, dW, dbias, B, d, K);
+    hipLaunchKernelGGL(head_bwd_t_kernel, dim3(K * ((d + 63) / 64)), dim3(256), 0, s, dlogits, xhat, dW, dbias, B, d, K);
     ECGVIT_CHECK_LAUNCH();
     hipLaunchKernelGGL(head_bwd_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, s, W, gamma, beta, dbias, dW, dgamma, dbeta, d, K);
     ECGVIT_CHECK_LAUNCH();
