@@ -16,7 +16,7 @@
 // LDS image for every [row][64 x bf16] tile (128-B rows):  16-B chunk index ^= bitrev3((row>>1)&7)
 //   -> ds_read_b128 row reads (MFMA K-contiguous operand) hit 16 distinct slots per 16-lane group, and
 //   -> ds_read_b64_tr_b16 reads of 4 consecutive rows x 64 B land in the 4 different 64-B quarters of the bank row.
-#include "common.cuh"
+#include "common.h"
 #include <cstdlib>
 
 namespace {

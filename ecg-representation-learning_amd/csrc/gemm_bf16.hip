@@ -16,7 +16,7 @@
 //   residual applied in f32, so C, aux and residual traffic is full-line.
 // Block order: 1-D grid remapped so that the 8 XCDs each own a contiguous run of tiles, N fastest: the blocks
 //   sharing an activation row-panel run on one XCD's L2; the (small) weight matrix streams from L2/MALL.
-#include "common.cuh"
+#include "common.h"
 #include <cstdlib>
 
 namespace {
@@ -304,6 +304,9 @@ inline int choose_splits(const ecgvit_gemm_desc *d, int ntile) {
 bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d);
 int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s);
+// large A . B^T products (gemm_nt.hip)
+bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d);
+int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g);
 
 static bool use_v2() {
     static const bool on = [] { const char *e = getenv("ECGVIT_GEMM_V2"); return !(e && e[0] == '0'); }();
@@ -334,6 +337,7 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
+    if (ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, s, 0);
     if (use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_v2_launch(d, s);
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     SplitK sk;
@@ -377,7 +381,8 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     if (!d) return ECGVIT_EINVAL;
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
-        if (d->dtype == ECGVIT_BF16 && use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
+        if (d->dtype == ECGVIT_BF16 && (ecgvit_gemm_nt_applicable(d) || (use_v2() && ecgvit_gemm_bf16_v2_applicable(d))))
+            return ecgvit_gemm_bf16_launch(d, as_stream(stream));
         // generic path: plain GEMM, then the stand-alone column-sum kernel over the stored output
         if (d->workspace_bytes < ecgvit_colsum_workspace(d->M, d->N)) return ECGVIT_EINVAL;
         ecgvit_gemm_desc g = *d;
@@ -390,3 +395,14 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
     return ECGVIT_EINVAL;
 }
+
+#ifdef ECGVIT_TOOLS
+// tools build only (libecgvit_hip_tools.so): pick the kernel behind one A . B^T call, for A/B timing inside one process.
+// kernel: 0 = the shipped dispatch, 1 = the retired LDS-patch kernel, 2 = gemm_nt_kernel with column groups of raster_g n-tiles
+extern "C" int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g) {
+    if (!d) return ECGVIT_EINVAL;
+    if (kernel == 1) return ecgvit_gemm_bf16_v2_applicable(d) ? ecgvit_gemm_bf16_v2_launch(d, as_stream(stream)) : ECGVIT_EINVAL;
+    if (kernel == 2) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt_launch(d, as_stream(stream), raster_g) : ECGVIT_EINVAL;
+    return ecgvit_gemm(d, stream);
+}
+#endif

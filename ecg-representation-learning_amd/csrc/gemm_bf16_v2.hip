@@ -21,7 +21,7 @@
 // Transposed reads are issued as inline asm: with an LDS-DMA in flight hipcc's waitcnt pass drains vmcnt(0) in front of the builtin.
 // Epilogue: accumulators -> per-wave LDS patch -> 128-B row segments with bias / GELU / GELU' / dropout / residual / x-aux / column
 // sums applied in f32 (same semantics as gemm_bf16.hip).
-#include "common.cuh"
+#include "common.h"
 #include <cstdlib>
 
 namespace {
@@ -1455,6 +1455,10 @@ inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
 }
 
 }  // namespace
+
+void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, partial, nparts, N, out);
+}
 
 bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d) {
     if ((d->epilogue & ECGVIT_EPI_COLSUM) &&

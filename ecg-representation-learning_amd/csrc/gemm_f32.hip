@@ -8,7 +8,7 @@
 // Tile 128x128x16, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 accumulators.
 // LDS images are k-major ([k][m]), so a fragment read is 32 consecutive floats per half-wave
 // (conflict-free ds_read_b32); operands that are K-contiguous in memory are transposed on the LDS write.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

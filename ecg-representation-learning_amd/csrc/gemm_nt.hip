@@ -1,0 +1,519 @@
+// C = epilogue(A . B^T) for the large Linear shapes of the train step (forward products and, against the transposed bf16 weight
+// shadows, the input-gradient products): M x N x K with both operands K-contiguous, K % 64 == 0, N % 8 == 0.
+//
+// gemm_nt_kernel ("R"): persistent, 256 x 256 x 64 block tile, 8 waves (2 x 4, wave tile 128 x 64), v_mfma_f32_16x16x32_bf16.
+//   * main loop: four 256-cycle phases per K-tile (one 64 x 32 output quadrant each: 12 / 4 / 8 / 0 ds_read_b128, nothing read
+//     twice); operands arrive as 16-KiB half-tiles by LDS-DMA (`buffer_load ... lds`) from a stream that runs CONTINUOUSLY across
+//     output tiles -- activations two K-tiles ahead in a 3-slot ring per half, weights one K-tile ahead in 2 slots (10 x 16 KiB = all
+//     of LDS), one counted vmcnt(4) per K-tile, never a drain; waves 4-7 run one barrier behind waves 0-3 (ping-pong per SIMD).
+//   * the MFMA takes the WEIGHT fragment as its first operand and the activation fragment as its second, so an accumulator
+//     register quad holds 4 consecutive output COLUMNS of one row (D row = 4*(lane>>4) + reg <-> n, D col = lane&15 <-> m).  The
+//     weight fragment of n-tile j reads image rows 32*(j>>1) + 8*(i>>2) + 4*(j&1) + (i&3) (i = lane&15), which makes the 16
+//     values a lane holds for one output row two runs of 8 consecutive columns (8q .. 8q+7 and 32+8q .. 32+8q+7, q = lane>>4):
+//     the epilogue runs straight out of the accumulators -- bias / GELU / dropout / residual / x-aux / column sums in f32, two
+//     16-B stores per lane and row (64 contiguous bytes per row and instruction) -- with no LDS round trip and no patch buffer.
+//     The kernel it replaces (gemm_bf16_q_kernel) drained through per-wave LDS patches: 256 KiB of ds_write_b32 per tile at
+//     64 B/clk plus the read-back, inside a 10.4k-cycle drain per tile (20 % of a K = 768 tile).
+//   * LDS images (the DMA destination is wave-uniform base + lane*16, so swizzles go on the per-lane SOURCE address):
+//     activations [128 rows][64 k], 16-B chunk ^= (row>>1)&7; weights chunk ^= (((row>>3)&3)<<1) | ((row>>1)&1) -- both
+//     conflict-free for their ds_read_b128 fragment patterns (rows 16t + (lane&15) / the permuted rows above).
+//   * epilogue flags are a template parameter for the combinations the train step uses (branch-free bodies); any other
+//     combination runs the same kernel with run-time flags.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 16384;
+constexpr int LDS_BYTES = 163840;
+
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// item -> tile origin.  Items are dealt XCD-contiguously (blocks b and b + 8 share an XCD, so XCD x walks one contiguous run of
+// tile ids); tile ids run over column groups of G n-tiles, m-major inside a group: the 32 tiles an XCD works on at a time share
+// ~32/G activation panels and G weight panels.
+__device__ __forceinline__ void decode_tile(int it, int ntile, int tiles_m, int tiles_n, int G, int &m0, int &n0) {
+    const int tid = xcd_remap(it, ntile);
+    const int full = G * tiles_m;
+    const int ng = (tiles_n + G - 1) / G;
+    int g = tid / full;
+    g = g < ng - 1 ? g : ng - 1;
+    const int rem = tid - g * full;
+    const int w = (g == ng - 1) ? tiles_n - g * G : G;
+    const int tm = rem / w, tn = g * G + (rem - tm * w);
+    m0 = tm * BM;
+    n0 = tn * BN;
+}
+
+#define NT_HAS(f) (((FL >= 0) ? FL : e.flags) & (f))
+
+// two f32 -> one dword of two bf16 (RNE, NaN-safe); written out because hipcc otherwise pairs the converts of an 8-element
+// run across odd register boundaries (5 converts + 4 v_perm/v_alignbit per 16-B store instead of 4 converts)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+
+// one run of 8 consecutive columns of one output row: v = alpha*acc -> bias -> GELU (+aux) -> dropout -> GELU' / x-aux -> residual
+// -> accumulate -> store; same order and rounding points as gemm_bf16.hip's epilogue_value.  All global accesses are buffer
+// operations: `off` is the byte offset of (m, n) in C scaled per buffer by the caller, 0x80000000 for a masked lane -- beyond
+// every descriptor's num_records, so loads return zero and stores are dropped, and the body needs no exec-mask branch.
+struct NtBufs {
+    __amdgpu_buffer_rsrc_t c, res, aux;
+    int ldc2, ldr2, ldx2;   // row pitches in bytes
+};
+constexpr uint32_t NT_OOB = 0x80000000u;
+
+template <typename TO, int FL>
+__device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, const NtBufs &bf, const EpiParams &e,
+                                        const u32x4 &res, const u32x4 &auxin, float *cs8) {
+    if (e.alpha != 1.f) {   // wave-uniform
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
+    }
+    if (NT_HAS(ECGVIT_EPI_BIAS)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+    }
+    if constexpr (sizeof(TO) == 2) {
+        float mult[8];
+        const bool drop = NT_HAS(ECGVIT_EPI_DROPOUT);
+        if (drop) dropout_mask8(e.seed, m * (uint32_t)e.N + ncol, e.drop_thresh, e.inv_keep, mult);
+        if (NT_HAS(ECGVIT_EPI_GELU)) {
+            u32x4 sav;
+            if (NT_HAS(ECGVIT_EPI_GELU_GRAD_AUX)) {
+                float dy[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    gelu_fast_both(v[k], v[k], dy[k]);
+                    if (drop) dy[k] *= mult[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sav[k] = pack_bf16x2(dy[2 * k], dy[2 * k + 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sav[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[2 * k] = gelu_fast(bf16_lo(sav[k])); v[2 * k + 1] = gelu_fast(bf16_hi(sav[k])); }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(sav, bf.aux, ok ? m * (uint32_t)bf.ldx2 + ncol * 2 : NT_OOB, 0, 0);
+        }
+        if (drop) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] *= mult[k];
+        }
+        if (NT_HAS(ECGVIT_EPI_GELU_BWD)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] *= gelu_fast_grad(bf16_lo(auxin[k])); v[2 * k + 1] *= gelu_fast_grad(bf16_hi(auxin[k])); }
+        }
+        if (NT_HAS(ECGVIT_EPI_MUL_AUX)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] *= bf16_lo(auxin[k]); v[2 * k + 1] *= bf16_hi(auxin[k]); }
+        }
+        if (NT_HAS(ECGVIT_EPI_RESIDUAL)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_lo(res[k]); v[2 * k + 1] += bf16_hi(res[k]); }
+        }
+        const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 2 : NT_OOB;
+        if (NT_HAS(ECGVIT_EPI_ACCUM)) {
+            const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_lo(old[k]); v[2 * k + 1] += bf16_hi(old[k]); }
+        }
+        u32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(out, bf.c, off, 0, 0);
+        if (NT_HAS(ECGVIT_EPI_COLSUM)) {   // of the values as stored; masked lanes add nothing
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { cs8[2 * k] += ok ? bf16_lo(out[k]) : 0.f; cs8[2 * k + 1] += ok ? bf16_hi(out[k]) : 0.f; }
+        }
+    } else {
+        const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
+        if (NT_HAS(ECGVIT_EPI_ACCUM)) {
+            const u32x4 o0 = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 0, 0), o1 = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 16, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] += __builtin_bit_cast(float, o0[k]); v[4 + k] += __builtin_bit_cast(float, o1[k]); }
+        }
+        u32x4 w0, w1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w0[k] = __builtin_bit_cast(uint32_t, v[k]); w1[k] = __builtin_bit_cast(uint32_t, v[4 + k]); }
+        __builtin_amdgcn_raw_buffer_store_b128(w0, bf.c, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w1, bf.c, off, 16, 0);
+    }
+}
+
+// Drain one wave's 128 x 64 accumulator block straight from registers.  acc[i][j][r] = C[row 16i + (lane&15)]
+// [col 32*(j>>1) + 8*(lane>>4) + 4*(j&1) + r] of the wave tile.
+template <typename TO, int FL>
+__device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gemm_desc &d, const EpiParams &e, const NtBufs &bf, int m0, int n0,
+                                            int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int c = lane & 15, q = lane >> 4;
+    const int M = d.M, N = d.N;
+    const int nb = n0 + wn * 64 + 8 * q;
+    const bool nok0 = nb < N, nok1 = nb + 32 < N;
+    const int nl0 = nok0 ? nb : 0, nl1 = nok1 ? nb + 32 : 0;   // in-range columns for the bias loads of masked lanes
+    float bias[16];
+    if (NT_HAS(ECGVIT_EPI_BIAS)) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(e.bias + nl0), b1 = *reinterpret_cast<const f32x4 *>(e.bias + nl0 + 4);
+        const f32x4 b2 = *reinterpret_cast<const f32x4 *>(e.bias + nl1), b3 = *reinterpret_cast<const f32x4 *>(e.bias + nl1 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { bias[k] = b0[k]; bias[4 + k] = b1[k]; bias[8 + k] = b2[k]; bias[12 + k] = b3[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bias[k] = 0.f;
+    }
+    float cs[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cs[k] = 0.f;
+    const uint32_t mrow = (uint32_t)(m0 + wm * 128 + c);
+    constexpr bool kBf = sizeof(TO) == 2;
+    constexpr bool kLight = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
+    const bool want_res = kBf && NT_HAS(ECGVIT_EPI_RESIDUAL), want_aux = kBf && NT_HAS(ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_GELU_BWD);
+    // rows >= M fall beyond num_records by themselves; masked columns are forced there
+    auto ld_res = [&](int i, int h) {
+        return want_res ? __builtin_amdgcn_raw_buffer_load_b128(bf.res, (h ? nok1 : nok0) ? (mrow + 16 * i) * (uint32_t)bf.ldr2 + (nb + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+    };
+    auto ld_aux = [&](int i, int h) {
+        return want_aux ? __builtin_amdgcn_raw_buffer_load_b128(bf.aux, (h ? nok1 : nok0) ? (mrow + 16 * i) * (uint32_t)bf.ldx2 + (nb + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+    };
+    if constexpr (kLight) {
+        // light bodies: every row load of the tile is issued up front (the 64 fragment registers are free now), then the 8 row steps
+        // run fully unrolled on the accumulators in place; stores are fire-and-forget
+        u32x4 R[8][2], X[8][2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) { R[i][h] = ld_res(i, h); X[i][h] = ld_aux(i, h); }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v0[8], v1[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
+            const uint32_t m = mrow + 16 * i;
+            const bool mok = (int)m < M;
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, R[i][0], X[i][0], cs);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, R[i][1], X[i][1], cs + 8);
+        }
+    } else {
+        // heavy bodies must exist ONCE in the instruction stream (I-cache): rolled loop, only the accumulator pick is a switch;
+        // row loads one step ahead
+        u32x4 nr0 = ld_res(0, 0), nr1 = ld_res(0, 1), na0 = ld_aux(0, 0), na1 = ld_aux(0, 1);
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+            const u32x4 r0 = nr0, r1 = nr1, a0 = na0, a1 = na1;
+            if (i < 7) { nr0 = ld_res(i + 1, 0); nr1 = ld_res(i + 1, 1); na0 = ld_aux(i + 1, 0); na1 = ld_aux(i + 1, 1); }
+            float v0[8], v1[8];
+#define NT_PICK(I)                                                                                       \
+    case I:                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                  \
+            v0[r] = acc[I][0][r]; v0[4 + r] = acc[I][1][r]; v1[r] = acc[I][2][r]; v1[4 + r] = acc[I][3][r]; \
+        }                                                                                                \
+        break;
+            switch (i) { NT_PICK(0) NT_PICK(1) NT_PICK(2) NT_PICK(3) NT_PICK(4) NT_PICK(5) NT_PICK(6) default: NT_PICK(7) }
+#undef NT_PICK
+            const uint32_t m = mrow + 16 * i;
+            const bool mok = (int)m < M;
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, r0, a0, cs);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, r1, a1, cs + 8);
+        }
+    }
+    if (NT_HAS(ECGVIT_EPI_COLSUM)) {
+        // lanes with equal (lane >> 4) hold the same 16 columns: fold the 16 rows, one partial row per (tile row, wm)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            cs[k] += __shfl_xor(cs[k], 1, 64);
+            cs[k] += __shfl_xor(cs[k], 2, 64);
+            cs[k] += __shfl_xor(cs[k], 4, 64);
+            cs[k] += __shfl_xor(cs[k], 8, 64);
+        }
+        if (c == 0) {
+            float *pr = reinterpret_cast<float *>(d.workspace) + ((int64_t)(m0 / BM) * 2 + wm) * N;
+            if (nok0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pr[nb + k] = cs[k];
+            }
+            if (nok1) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pr[nb + 32 + k] = cs[8 + k];
+            }
+        }
+    }
+}
+
+template <typename TO, int FL>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const int M = d.M, N = d.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wm == 1;
+    const int nk = d.K / BK;
+    const int lda2 = (int)d.lda * 2, ldb2 = (int)d.ldb * 2;   // row pitches in bytes
+    const int ntile = tiles_m * tiles_n;
+
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)M * lda2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
+    NtBufs bf;
+    bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * 2;
+    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);
+    bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
+    bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
+    // this wave's two DMA pieces of a half-tile: rows 16*wave + {0..7}, {8..15}; LDS chunk p of row r holds source chunk p ^ f(r)
+    const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8, p = lane & 7;
+    const int voA0 = r0 * lda2 + ((p ^ ((r0 >> 1) & 7)) << 4), voA1 = r1 * lda2 + ((p ^ ((r1 >> 1) & 7)) << 4);
+    const int fw0 = (((r0 >> 3) & 3) << 1) | ((r0 >> 1) & 1), fw1 = (((r1 >> 3) & 3) << 1) | ((r1 >> 1) & 1);
+    const int voB0 = r0 * ldb2 + ((p ^ fw0) << 4), voB1 = r1 * ldb2 + ((p ^ fw1) << 4);
+    // fragment read offsets inside a half-tile image; the second 32-deep k-step (s = 1) is ^ 64
+    const int fr = lane & 15, fq = lane >> 4;
+    const int loff = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);                 // activations: row 16t + fr, tile t adds 2048
+    const int rl = 8 * (fr >> 2) + (fr & 3);
+    const int boff = (wn & 1) * 8192 + rl * 128 + ((fq ^ (((fr >> 2) << 1) | ((fr >> 1) & 1))) << 4);   // weights: n-tile j adds 512*(j&1) + 4096*(j>>1)
+
+#define R_DMA_A(h, ring, soff)                                                                                                   \
+    do {                                                                                                                         \
+        char *dst_ = smem + (3 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                       \
+        const int so_ = (soff) + (h) * 128 * lda2;                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst_, 16, voA0, so_, 0, 0);                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dst_ + 1024), 16, voA1, so_, 0, 0);                               \
+    } while (0)
+#define R_DMA_B(h, ring, soff)                                                                                                   \
+    do {                                                                                                                         \
+        char *dst_ = smem + (6 + 2 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                   \
+        const int so_ = (soff) + (h) * 128 * ldb2;                                                                               \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst_, 16, voB0, so_, 0, 0);                                        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst_ + 1024), 16, voB1, so_, 0, 0);                               \
+    } while (0)
+#define R_PHASE_SYNC_A()                                   \
+    do {                                                   \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_setprio(1);                     \
+    } while (0)
+#define R_PHASE_SYNC_B()                   \
+    do {                                   \
+        __builtin_amdgcn_s_setprio(0);     \
+        __builtin_amdgcn_sched_barrier(0); \
+        __builtin_amdgcn_s_barrier();      \
+        __builtin_amdgcn_sched_barrier(0); \
+    } while (0)
+
+    int cm0, cn0, nm0, nn0;
+    decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
+    nm0 = cm0; nn0 = cn0;
+    // producer cursors: byte offset of (tile row, k) in the scalar offset; per-lane offsets never change
+    int a_it = it, a_kt = 0, a_base = cm0 * lda2;
+    int b_it = it, b_kt = 0, b_base = cn0 * ldb2;
+    bool a_ok = true, b_ok = true;
+#define R_ADV_A()                                                                                         \
+    do {                                                                                                  \
+        if (++a_kt == nk) {                                                                               \
+            a_kt = 0;                                                                                     \
+            a_it += (int)gridDim.x;                                                                       \
+            if (a_it < nitems) { decode_tile(a_it, ntile, tiles_m, tiles_n, ngroup, nm0, nn0); a_base = nm0 * lda2; } \
+            else a_ok = false;                                                                            \
+        }                                                                                                 \
+    } while (0)
+#define R_ADV_B()                                          \
+    do {                                                   \
+        if (++b_kt == nk) {                                \
+            b_kt = 0;                                      \
+            b_it += (int)gridDim.x;                        \
+            if (b_it < nitems) b_base = nn0 * ldb2;        \
+            else b_ok = false;                             \
+        }                                                  \
+    } while (0)
+
+    // ---- prologue: A(0), B(0), A(1)
+    R_DMA_A(0, 0, a_base); R_DMA_A(1, 0, a_base); R_ADV_A();
+    R_DMA_B(0, 0, b_base); R_DMA_B(1, 0, b_base); R_ADV_B();
+    R_DMA_A(0, 1, a_base + a_kt * (BK * 2)); R_DMA_A(1, 1, a_base + a_kt * (BK * 2)); R_ADV_A();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    int ga = 0, gb = 0;   // ring slots of the K-tile being multiplied
+    for (;;) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int sa = (3 * wm + ga) * HALF_BYTES + loff;          // byte offsets into smem (kept integral: LDS address space)
+            const int sb = (6 + 2 * (wn >> 1) + gb) * HALF_BYTES + boff;
+            const int ga2 = ga == 0 ? 2 : ga - 1;   // (g + 2) % 3
+            const int gb1 = gb ^ 1;
+            bf16x8 a[4][2], b0[2][2], b1[2][2];
+            // ---------------- phase 1: rows 0-63 x n-tiles 0,1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b0[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + j * 512) ^ (s * 64)));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
+            if (b_ok) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+            R_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][s], a[i][s], acc[i][j], 0, 0, 0);
+            R_PHASE_SYNC_B();
+            // ---------------- phase 2: rows 0-63 x n-tiles 2,3
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (s * 64)));
+            if (b_ok) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
+            R_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][s], a[i][s], acc[i][2 + j], 0, 0, 0);
+            R_PHASE_SYNC_B();
+            // ---------------- phase 3: rows 64-127 x n-tiles 2,3
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (s * 64)));
+            const bool a_issue = a_ok;
+            if (a_issue) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+            R_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][s], a[i][s], acc[4 + i][2 + j], 0, 0, 0);
+            R_PHASE_SYNC_B();
+            // ---------------- phase 4: rows 64-127 x n-tiles 0,1 (no LDS reads); the K-tile's one counted wait: all but A(kt+2) landed
+            if (a_issue) {
+                R_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
+                R_ADV_A();
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            R_PHASE_SYNC_A();
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][s], a[i][s], acc[4 + i][j], 0, 0, 0);
+            R_PHASE_SYNC_B();
+            ga = ga == 2 ? 0 : ga + 1;
+            gb ^= 1;
+        }
+        // ---------------- output tile done: both wave groups drain together, straight from the accumulators (no LDS involved, so
+        // the operand stream of the next tile -- A two K-tiles, B one K-tile ahead -- stays in flight underneath)
+        const int next_it = it + (int)gridDim.x;
+        const bool has_next = next_it < nitems;
+        if (!late) __builtin_amdgcn_s_barrier();     // leading group: wait for the trailing group's last MFMA phase
+        nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane);
+        if (late && has_next) __builtin_amdgcn_s_barrier();   // trailing group falls one barrier behind again
+        if (!has_next) break;
+        it = next_it;
+        if (a_it == it) { cm0 = nm0; cn0 = nn0; }                     // the producer cursor already decoded this item
+        else decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
+    }
+#undef R_DMA_A
+#undef R_DMA_B
+#undef R_PHASE_SYNC_A
+#undef R_PHASE_SYNC_B
+#undef R_ADV_A
+#undef R_ADV_B
+}
+
+// n-tiles per column group: the weight panels of one group (G x 256 x K bf16) should sit in about half of an XCD's 4-MiB L2; the
+// activation operand is then re-read once per group, so only group when that costs less than the weight re-fetches it saves
+int choose_group(const ecgvit_gemm_desc *d, int tiles_n, int ntile) {
+    const double a_bytes = 2.0 * d->M * d->K, b_bytes = 2.0 * d->N * d->K;
+    const double rounds = std::max(1.0, (double)ntile / 256.0);
+    int best = tiles_n;
+    double best_cost = a_bytes + b_bytes * 8.0 * rounds;
+    for (int G = 1; G < tiles_n; ++G) {
+        if (2.0 * G * 256.0 * d->K > 2.2e6) break;
+        const int ng = (tiles_n + G - 1) / G;
+        const double cost = a_bytes * ng + b_bytes * 8.0;
+        if (cost < best_cost) { best_cost = cost; best = G; }
+    }
+    return best;
+}
+
+}  // namespace
+
+bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
+    if (d->layout != ECGVIT_GEMM_NT || d->dtype != ECGVIT_BF16) return false;
+    if (d->batch1 != 1 || d->batch2 != 1) return false;
+    if (d->M < 2048 || d->N < 128 || d->N % 8 != 0 || d->K % 64 != 0 || d->K < 192) return false;
+    if ((int64_t)d->M * d->lda * 2 + 65536 * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldb * 2 + 65536 * d->ldb >= (1ll << 31)) return false;
+    const int64_t esz = d->out_dtype == ECGVIT_BF16 ? 2 : 4, rows = (int64_t)d->M + 256;   // epilogue offsets are 32-bit byte offsets
+    if (rows * d->ldc * esz >= (1ll << 31) || rows * d->ldr * 2 >= (1ll << 31) || rows * d->ldaux * 2 >= (1ll << 31)) return false;
+    if (d->epilogue & ECGVIT_EPI_COLSUM) {
+        if (d->out_dtype != ECGVIT_BF16 || !d->workspace || !d->colsum_out ||
+            d->workspace_bytes < (int64_t)8 * ((d->M + BM - 1) / BM) * d->N)
+            return false;
+    }
+    return true;
+}
+
+void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s);   // gemm_bf16_v2.hip
+
+// argument validation is done by the caller (ecgvit_gemm_bf16_launch); raster_g <= 0 selects the built-in choice
+int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g) {
+    const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : choose_group(d, tiles_n, ntile);
+    const EpiParams e = make_epi(d);
+    const dim3 grid((unsigned)std::min(ntile, 256)), block(512);
+    const int fl = d->epilogue;
+    constexpr int F_LIN = ECGVIT_EPI_BIAS | ECGVIT_EPI_RESIDUAL;
+    constexpr int F_UP = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX;
+    constexpr int F_DH = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM;
+#define NT_LAUNCH(TO, FL) hipLaunchKernelGGL((gemm_nt_kernel<TO, FL>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile)
+    if (d->out_dtype == ECGVIT_BF16) {
+        switch (fl) {
+            case 0: NT_LAUNCH(bf16_t, 0); break;
+            case F_LIN: NT_LAUNCH(bf16_t, F_LIN); break;
+            case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH(bf16_t, F_LIN | ECGVIT_EPI_DROPOUT); break;
+            case F_UP: NT_LAUNCH(bf16_t, F_UP); break;
+            case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_DROPOUT); break;
+            case F_DH: NT_LAUNCH(bf16_t, F_DH); break;
+            default: NT_LAUNCH(bf16_t, -1); break;
+        }
+    } else {
+        if (fl == 0) NT_LAUNCH(float, 0);
+        else NT_LAUNCH(float, -1);
+    }
+#undef NT_LAUNCH
+    ECGVIT_CHECK_LAUNCH();
+    if (d->epilogue & ECGVIT_EPI_COLSUM) {
+        ecgvit_colsum_reduce_launch((const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out, s);
+        ECGVIT_CHECK_LAUNCH();
+    }
+    return ECGVIT_OK;
+}

@@ -1,7 +1,7 @@
 // Classification head (CLS row -> LayerNorm -> Linear(d,K)), BCE-with-logits, and the fused
 // global-norm clip + AdamW step over flat f32 buffers.  Small or HBM-bound; all f32 except the
 // activation tensor X / dX (template T) and the optional bf16 shadow weights.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
 // Masked pre-train objective pieces (SimMIM-style; the build's own definition -- the reference has no masked
 // objective): mask-token substitution + positional add, row gather / scatter by host-generated
 // int32 indices (bit-exact integer indexing), L1 reconstruction loss.  All HBM-bound, 16 B per lane.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

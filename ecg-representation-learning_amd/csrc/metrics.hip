@@ -2,7 +2,7 @@
 // (ecg_transformer/util/train.py:12-56: sklearn accuracy / balanced accuracy / classification_report recalls / per-class
 // roc_auc_score), so a train or eval step never ships (B, 71) logits to the host and never calls sklearn.
 // Everything the device produces is an exact integer count; the handful of divisions happen on the host in double.
-#include "common.cuh"
+#include "common.h"
 
 // counts[0..3] = tp, tn, fp, fn over all B*K (prediction = prob >= 0.5, util/train.py:23); counts[4 + c] = positives of class c
 __device__ __forceinline__ float as_prob(float s, int from_logits) { return from_logits ? 1.0f / (1.0f + expf(-s)) : s; }

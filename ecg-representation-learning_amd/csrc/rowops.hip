@@ -2,7 +2,7 @@
 // column sums (bias grads), row softmax (f32 parity path).  All are templated on the activation type
 // (float = parity path, bf16 = throughput path), move 16 B per lane per access, reduce with wave64
 // shuffles (one row per wave), and keep statistics / parameter gradients in f32.
-#include "common.cuh"
+#include "common.h"
 
 namespace {
 

@@ -132,10 +132,10 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 # thin wrappers (argument marshalling only)
 # ------------------------------------------------------------------------------------------------
-def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
-         alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-         a_off=0, b_off=0, c_off=0, colsum_out=None):
-    """A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
+def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
+              alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
+              a_off=0, b_off=0, c_off=0, colsum_out=None):
+    """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
     d = GemmDesc()
     d.layout, d.dtype, d.out_dtype, d.epilogue = layout, code(A.dtype), code(C.dtype), epilogue
@@ -148,6 +148,12 @@ def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, resi
     d.colsum_out = ptr(colsum_out)
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    return d
+
+
+def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw):
+    """C = epilogue(alpha * op(A) . op(B)); keyword arguments as `gemm_desc`."""
+    d = gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw)
     check(lib().ecgvit_gemm(byref(d), stream()), 'ecgvit_gemm')
 
 

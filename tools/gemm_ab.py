@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""A/B timing of the large A.B^T kernels on the eight Linear products of one EcgVit-base layer (M = 512*251 token rows), WITH the
+epilogues the train step uses, all variants interleaved in ONE process on ONE device (guide rule 24).
+
+Needs the tools build (`make -C ecg-representation-learning_amd/csrc tools`): `ecgvit_tools_gemm(desc, stream, kernel, raster_g)`
+kernel 1 = retired LDS-patch kernel (gemm_bf16_q_kernel), 2 = gemm_nt_kernel; `lib` = torch.matmul (hipBLASLt), plain product only.
+usage: python tools/gemm_ab.py [--rounds 5] [--iters 10] [--groups 0,1,3] [--check]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('ECGVIT_HIP_LIB', os.path.join(ROOT, 'ecg-representation-learning_amd', 'libecgvit_hip_tools.so'))
+import ecg_representation_learning_amd as E  # noqa: E402,F401
+from ecg_representation_learning_amd import hip  # noqa: E402
+from ecg_representation_learning_amd.hip import (EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM,  # noqa: E402
+                                                  EPI_GELU_GRAD_AUX, EPI_MUL_AUX, GEMM_NT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rounds', type=int, default=5)
+    ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--m', type=int, default=512 * 251)
+    ap.add_argument('--groups', default='0', help='comma list of raster_g values for kernel 2 (0 = built-in choice)')
+    ap.add_argument('--check', action='store_true', help='compare kernel 2 with kernel 1 and with an f32 reference on a row sample')
+    ap.add_argument('--no-old', action='store_true')
+    ap.add_argument('--no-lib', action='store_true')
+    ap.add_argument('--only', default='')
+    ap.add_argument('--plain', action='store_true', help='also time every epilogue case with epilogue 0')
+    ap.add_argument('--json', default='')
+    args = ap.parse_args()
+    lib = hip.lib()
+    tg = lib.ecgvit_tools_gemm
+    tg.restype, tg.argtypes = ctypes.c_int, [ctypes.POINTER(hip.GemmDesc), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    M, d, f = args.m, 768, 3072
+    LIN = EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT
+    UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT
+    DH = EPI_MUL_AUX | EPI_COLSUM
+    cases = [('fwd qkv', d, 3 * d, 0), ('fwd out', d, d, LIN), ('fwd ffn_up', d, f, UP), ('fwd ffn_down', f, d, LIN),
+             ('dgrad qkv', 3 * d, d, 0), ('dgrad out', d, d, 0), ('dgrad ffn_up', f, d, 0), ('dgrad ffn_down', d, f, DH)]
+    if args.plain:
+        cases += [(n + ' [plain]', K, N, 0) for (n, K, N, e_) in cases if e_]
+    if args.only:
+        cases = [c for c in cases if args.only in c[0]]
+    groups = [int(g) for g in args.groups.split(',')]
+    bf = torch.bfloat16
+    dev = 'cuda'
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    results = []
+    for name, K, N, epi in cases:
+        torch.manual_seed(1)
+        X = torch.randn(M, K, device=dev).to(bf)
+        W = (torch.randn(N, K, device=dev) * 0.03).to(bf)
+        bias = torch.randn(N, device=dev) * 0.1
+        res = torch.randn(M, N, device=dev).to(bf) if epi & EPI_RESIDUAL else None
+        aux = (torch.rand(M, N, device=dev) * 1.2).to(bf) if epi & (EPI_GELU | EPI_MUL_AUX) else None
+        cso = torch.zeros(N, device=dev) if epi & EPI_COLSUM else None
+        outs = {}
+
+        def make(C, auxbuf):
+            return hip.gemm_desc(GEMM_NT, X, W, C, M, N, K, K, K, N, epilogue=epi, bias=bias if epi & EPI_BIAS else None, residual=res,
+                                 ldr=N, aux=auxbuf, ldaux=N, dropout_p=0.1 if epi & EPI_DROPOUT else 0.0, seed=1234, workspace=ws,
+                                 colsum_out=cso)
+
+        variants = []
+        if not args.no_old:
+            variants.append(('old', 1, 0))
+        for g in groups:
+            variants.append((f'new g={g}', 2, g))
+        C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
+        A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
+        descs = {v[0]: make(C[v[0]], A[v[0]]) for v in variants}
+        st = torch.cuda.current_stream().cuda_stream
+
+        def run(v):
+            rc = tg(ctypes.byref(descs[v[0]]), st, v[1], v[2])
+            if rc:
+                raise RuntimeError(f'{name} {v[0]}: rc={rc}')
+
+        fns = [(v[0], (lambda v=v: run(v))) for v in variants]
+        if not args.no_lib:
+            Cl = torch.empty(M, N, device=dev, dtype=bf)
+            fns.append(('lib plain', lambda: torch.matmul(X, W.t(), out=Cl)))
+        times = {n: [] for n, _ in fns}
+        for n, fn in fns:
+            for _ in range(2):
+                fn()
+        torch.cuda.synchronize()
+        for _ in range(args.rounds):
+            for n, fn in fns:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                times[n].append(e0.elapsed_time(e1) / args.iters * 1e3)
+        fl = 2.0 * M * K * N
+        for n, _ in fns:
+            t = sorted(times[n])
+            med, mn = t[len(t) // 2], t[0]
+            print(f'{name:15s} K={K:4d} N={N:4d} epi={epi:3d}  {n:10s}: median {med:7.1f} us  min {mn:7.1f} us  {fl / med / 1e6:7.1f} TFLOP/s '
+                  f'({100 * fl / med / 1e6 / 2500:4.1f} %)', flush=True)
+            results.append(dict(case=name, K=K, N=N, epilogue=epi, variant=n, median_us=med, min_us=mn, tflops=fl / med / 1e6))
+        if args.check and len(variants) >= 2 and variants[0][0] == 'old':
+            ref = C['old'].float()
+            for v in variants[1:]:
+                dlt = (C[v[0]].float() - ref).abs()
+                same = (C[v[0]] == C['old']).float().mean().item()
+                msg = f'   check {v[0]}: max|new-old| {dlt.max().item():.3e}  identical {100 * same:.4f} %'
+                if aux is not None and epi & EPI_GELU:
+                    msg += f'  aux identical {100 * (A[v[0]] == A["old"]).float().mean().item():.4f} %'
+                print(msg, flush=True)
+        if args.check:
+            # f32 reference on a row sample (plain product + bias only cases get the full check elsewhere: tests/test_gpu_ops.py)
+            rows = torch.randint(0, M, (512,), device=dev)
+            acc = X[rows].float() @ W.float().t()
+            if epi == 0:
+                for v in variants:
+                    err = (C[v[0]][rows].float() - acc).abs().max().item()
+                    print(f'   check {v[0]} vs f32 reference (512 rows): max abs err {err:.3e}', flush=True)
+    if args.json:
+        with open(args.json, 'w') as fh:
+            json.dump(results, fh, indent=1)
+
+
+if __name__ == '__main__':
+    main()
