@@ -306,7 +306,7 @@ int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s);
 // large A . B^T products (gemm_nt.hip)
 bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d);
-int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g);
+int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);
 
 static bool use_v2() {
     static const bool on = [] { const char *e = getenv("ECGVIT_GEMM_V2"); return !(e && e[0] == '0'); }();
@@ -337,7 +337,7 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
-    if (ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, s, 0);
+    if (ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, s, 0, 0);
     if (use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_v2_launch(d, s);
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     SplitK sk;
@@ -399,10 +399,11 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
 #ifdef ECGVIT_TOOLS
 // tools build only (libecgvit_hip_tools.so): pick the kernel behind one A . B^T call, for A/B timing inside one process.
 // kernel: 0 = the shipped dispatch, 1 = the retired LDS-patch kernel, 2 = gemm_nt_kernel with column groups of raster_g n-tiles
-extern "C" int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g) {
+// (0 = built-in choice) and diag bits (1 = stamped build, 2 = stores dropped)
+extern "C" int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g, int diag) {
     if (!d) return ECGVIT_EINVAL;
     if (kernel == 1) return ecgvit_gemm_bf16_v2_applicable(d) ? ecgvit_gemm_bf16_v2_launch(d, as_stream(stream)) : ECGVIT_EINVAL;
-    if (kernel == 2) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt_launch(d, as_stream(stream), raster_g) : ECGVIT_EINVAL;
+    if (kernel == 2) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt_launch(d, as_stream(stream), raster_g, diag) : ECGVIT_EINVAL;
     return ecgvit_gemm(d, stream);
 }
 #endif

@@ -20,6 +20,7 @@
 //   * epilogue flags are a template parameter for the combinations the train step uses (branch-free bodies); any other
 //     combination runs the same kernel with run-time flags.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -250,8 +251,16 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
     }
 }
 
-template <typename TO, int FL>
-__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems) {
+#ifdef ECGVIT_TOOLS
+// diagnostics (tools build only): per block {s_memtime, s_memrealtime} at start and end, cycles summed over main loops and epilogues
+__device__ unsigned long long g_nt_stamps[256 * 8];
+#define NT_STAMP_T() (STAMP ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define NT_STAMP_T() 0ull
+#endif
+
+template <typename TO, int FL, bool STAMP = false>
+__global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems, int ablate) {
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int M = d.M, N = d.N;
     const int lane = threadIdx.x & 63;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
     NtBufs bf;
     bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * 2;
-    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);
+    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (STAMP && (ablate & 1)) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1 (diagnostics): stores dropped
     bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
     bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
     // this wave's two DMA pieces of a half-tile: rows 16*wave + {0..7}, {8..15}; LDS chunk p of row r holds source chunk p ^ f(r)
@@ -348,7 +357,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     if (late) __builtin_amdgcn_s_barrier();
 
     int ga = 0, gb = 0;   // ring slots of the K-tile being multiplied
+    bool pre = false;     // the coming K-tile's DMA pieces were issued ahead of the previous tile's epilogue
+    // VMEM instructions the epilogue leaves in flight at least: its output stores (masked lanes still issue)
+    constexpr int NST = (sizeof(TO) == 2 ? 16 : 32) + ((FL >= 0 && (FL & ECGVIT_EPI_GELU)) ? 16 : 0);
+    [[maybe_unused]] unsigned long long st_t0 = 0, st_r0 = 0, st_main = 0, st_epi = 0, st_ntile = 0;
+#ifdef ECGVIT_TOOLS
+    if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     for (;;) {
+        [[maybe_unused]] const unsigned long long st_a = NT_STAMP_T();
         f32x4 acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -362,6 +379,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             const int ga2 = ga == 0 ? 2 : ga - 1;   // (g + 2) % 3
             const int gb1 = gb ^ 1;
             bf16x8 a[4][2], b0[2][2], b1[2][2];
+            const bool pre_k = pre;
+            pre = false;
+            const bool b_issue = b_ok && !pre_k;
             // ---------------- phase 1: rows 0-63 x n-tiles 0,1
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
-            if (b_ok) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+            if (b_issue) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
             R_PHASE_SYNC_A();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (s * 64)));
-            if (b_ok) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
+            if (b_issue) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
             R_PHASE_SYNC_A();
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -400,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (s * 64)));
-            const bool a_issue = a_ok;
+            const bool a_issue = a_ok && !pre_k;
             if (a_issue) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
             R_PHASE_SYNC_A();
 #pragma unroll
@@ -415,6 +435,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
                 R_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
                 R_ADV_A();
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (pre_k) {
+                // first K-tile after an epilogue: B(1) and A(2) went out BEFORE the epilogue's stores, so B(1) (needed next) is older
+                // than A(2) + the NST stores -- the stores stay in flight across this K-tile instead of being waited for here
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -434,35 +458,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         const int next_it = it + (int)gridDim.x;
         const bool has_next = next_it < nitems;
         if (!late) __builtin_amdgcn_s_barrier();     // leading group: wait for the trailing group's last MFMA phase
+        // Every fragment read of the last K-tile is done (reads precede their phase's MFMAs): its ring slots are free.  Issue what
+        // the next tile's K-tile 0 would issue -- B(1), A(2) -- NOW, ahead of the epilogue's stores.  vmcnt retires in issue order, and
+        // a CU takes ~10k cycles to push a 128-KiB tile out (12.6 B/clk: DESIGN.md 4), so a counted wait that sits BEHIND the stores
+        // stalls the next main loop until they are acknowledged; this way the first wait that covers them comes two K-tiles later.
+        if (a_ok && b_ok && has_next) {
+            R_DMA_B(0, gb ^ 1, b_base + b_kt * (BK * 2)); R_DMA_B(1, gb ^ 1, b_base + b_kt * (BK * 2)); R_ADV_B();
+            const int gaf = ga == 0 ? 2 : ga - 1;
+            R_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); R_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); R_ADV_A();
+            pre = true;
+        }
+        [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
         nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane);
+        if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
         if (late && has_next) __builtin_amdgcn_s_barrier();   // trailing group falls one barrier behind again
         if (!has_next) break;
         it = next_it;
         if (a_it == it) { cm0 = nm0; cn0 = nn0; }                     // the producer cursor already decoded this item
         else decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
     }
+#ifdef ECGVIT_TOOLS
+    if constexpr (STAMP) {
+        if (threadIdx.x == 0) {
+            unsigned long long *o = g_nt_stamps + blockIdx.x * 8;
+            o[0] = st_t0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+            o[4] = st_main; o[5] = st_epi; o[6] = st_ntile; o[7] = (unsigned long long)nk;
+        }
+    }
+#endif
 #undef R_DMA_A
 #undef R_DMA_B
 #undef R_PHASE_SYNC_A
 #undef R_PHASE_SYNC_B
 #undef R_ADV_A
 #undef R_ADV_B
-}
-
-// n-tiles per column group: the weight panels of one group (G x 256 x K bf16) should sit in about half of an XCD's 4-MiB L2; the
-// activation operand is then re-read once per group, so only group when that costs less than the weight re-fetches it saves
-int choose_group(const ecgvit_gemm_desc *d, int tiles_n, int ntile) {
-    const double a_bytes = 2.0 * d->M * d->K, b_bytes = 2.0 * d->N * d->K;
-    const double rounds = std::max(1.0, (double)ntile / 256.0);
-    int best = tiles_n;
-    double best_cost = a_bytes + b_bytes * 8.0 * rounds;
-    for (int G = 1; G < tiles_n; ++G) {
-        if (2.0 * G * 256.0 * d->K > 2.2e6) break;
-        const int ng = (tiles_n + G - 1) / G;
-        const double cost = a_bytes * ng + b_bytes * 8.0;
-        if (cost < best_cost) { best_cost = cost; best = G; }
-    }
-    return best;
 }
 
 }  // namespace
@@ -485,16 +514,33 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
 void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s);   // gemm_bf16_v2.hip
 
 // argument validation is done by the caller (ecgvit_gemm_bf16_launch); raster_g <= 0 selects the built-in choice
-int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g) {
+int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {
+#ifdef ECGVIT_TOOLS
+    {   // tools build only: whole-step A/B of the diag bits (bench.py under ECGVIT_HIP_LIB=libecgvit_hip_tools.so)
+        static const int env_diag = [] { const char *e = getenv("ECGVIT_NT_DIAG"); return e ? atoi(e) : 0; }();
+        diag |= env_diag;
+    }
+#endif
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
-    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : choose_group(d, tiles_n, ntile);
+    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : tiles_n;
     const EpiParams e = make_epi(d);
     const dim3 grid((unsigned)std::min(ntile, 256)), block(512);
     const int fl = d->epilogue;
     constexpr int F_LIN = ECGVIT_EPI_BIAS | ECGVIT_EPI_RESIDUAL;
     constexpr int F_UP = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX;
     constexpr int F_DH = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM;
-#define NT_LAUNCH(TO, FL) hipLaunchKernelGGL((gemm_nt_kernel<TO, FL>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile)
+#define NT_LAUNCH(TO, FL) hipLaunchKernelGGL((gemm_nt_kernel<TO, FL>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
+#ifdef ECGVIT_TOOLS
+    if ((diag & 1) && d->out_dtype == ECGVIT_BF16) {   // stamped diagnostic instantiations; diag & 2: output stores dropped
+        const int ab = (diag >> 1) & 1;
+        if (fl == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
+        else if (fl == (F_UP | ECGVIT_EPI_DROPOUT)) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
+        else if (fl == F_DH) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_DH, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
+        else return ECGVIT_EINVAL;
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
+#endif
     if (d->out_dtype == ECGVIT_BF16) {
         switch (fl) {
             case 0: NT_LAUNCH(bf16_t, 0); break;
@@ -517,3 +563,9 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     }
     return ECGVIT_OK;
 }
+
+#ifdef ECGVIT_TOOLS
+extern "C" int ecgvit_tools_nt_stamps(unsigned long long *h_out) {   // host buffer of 256*8 words
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? ECGVIT_OK : ECGVIT_ELAUNCH;
+}
+#endif

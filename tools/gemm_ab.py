@@ -38,7 +38,7 @@ def main():
     args = ap.parse_args()
     lib = hip.lib()
     tg = lib.ecgvit_tools_gemm
-    tg.restype, tg.argtypes = ctypes.c_int, [ctypes.POINTER(hip.GemmDesc), ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    tg.restype, tg.argtypes = ctypes.c_int, [ctypes.POINTER(hip.GemmDesc), ctypes.c_void_p] + [ctypes.c_int] * 3
     M, d, f = args.m, 768, 3072
     LIN = EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT
     UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT
@@ -71,16 +71,16 @@ def main():
 
         variants = []
         if not args.no_old:
-            variants.append(('old', 1, 0))
+            variants.append(('old', 1, 0, 0))
         for g in groups:
-            variants.append((f'new g={g}', 2, g))
+            variants.append((f'new g={g}', 2, g, 0))
         C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
         A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
         descs = {v[0]: make(C[v[0]], A[v[0]]) for v in variants}
         st = torch.cuda.current_stream().cuda_stream
 
         def run(v):
-            rc = tg(ctypes.byref(descs[v[0]]), st, v[1], v[2])
+            rc = tg(ctypes.byref(descs[v[0]]), st, v[1], v[2], v[3])
             if rc:
                 raise RuntimeError(f'{name} {v[0]}: rc={rc}')
 
@@ -106,7 +106,7 @@ def main():
         for n, _ in fns:
             t = sorted(times[n])
             med, mn = t[len(t) // 2], t[0]
-            print(f'{name:15s} K={K:4d} N={N:4d} epi={epi:3d}  {n:10s}: median {med:7.1f} us  min {mn:7.1f} us  {fl / med / 1e6:7.1f} TFLOP/s '
+            print(f'{name:15s} K={K:4d} N={N:4d} epi={epi:3d}  {n:16s}: median {med:7.1f} us  min {mn:7.1f} us  {fl / med / 1e6:7.1f} TFLOP/s '
                   f'({100 * fl / med / 1e6 / 2500:4.1f} %)', flush=True)
             results.append(dict(case=name, K=K, N=N, epilogue=epi, variant=n, median_us=med, min_us=mn, tflops=fl / med / 1e6))
         if args.check and len(variants) >= 2 and variants[0][0] == 'old':
