@@ -12,11 +12,16 @@ Workload at every N: EcgVit-base, bf16 MFMA path, 512 records x 12 leads x 5000 
 (BASELINE.json configs[2]/[3]; weak scaling: global batch = 512 * N).
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline      dominant kernel (the bf16 MFMA GEMM of the Linear forward passes): algorithmic FLOPs of its launches
-                / their HIP-event time measured inside the timed region, against the 2.5 PFLOP/s dense bf16 peak.
+  roofline      dominant kernel (gemm_nt_kernel: the bf16 MFMA A.B^T GEMM of the Linear forward and input-gradient products):
+                algorithmic FLOPs of its launches / their HIP-event time measured inside the timed region, against the
+                2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes, null
+                (with the reason in `traffic_source`) when the kernel sources changed since that profile was taken.
+  masked        (N = 1, default workload) the build's masked pre-train step timed in the same process: value, ms_per_step, roofline.
   cpu_baseline  the CPU oracle's train step (torch eager f32, all host cores) on a bounded sample of the same workload.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -64,7 +69,7 @@ class GemmProbe:
 
         def gemm(layout, A, B, C, M, N, K, *a, **k):
             hit = (probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and A.dtype == torch.bfloat16
-                   and K % 64 == 0 and M >= 2048 and N >= 256)   # the launches that dispatch to the persistent kernel symbol
+                   and K % 64 == 0 and K >= 192 and M >= 2048 and N >= 128)   # = ecgvit_gemm_nt_applicable: the launches of gemm_nt_kernel
             if hit:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -79,6 +84,10 @@ class GemmProbe:
         self._eng_hip = eng.hip
         eng.hip.gemm = gemm
 
+    def uninstall(self):
+        self.hip.gemm = self.orig
+        self._eng_hip.gemm = self.orig
+
     def result(self):
         if not self.events:
             return None
@@ -88,23 +97,40 @@ class GemmProbe:
                     flops_per_launch=self.flops / n)
 
 
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel sources and the C-ABI header: identifies the build a profile was taken on"""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, 'ecg-representation-learning_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.h')) + [os.path.join(ROOT, 'include', 'ecgvit_hip.h')]):
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_key, args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
-    calibration + WRITE_SIZE; tools/pmc_bench.sh).  Counters cannot be read from inside the process, so this is the value
-    measured on this same command line; null when the run differs from the profiled workload."""
-    if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512) or args.objective != 'supervised':
-        return None
-    path = os.path.join(ROOT, 'profiles', 'r01_f_pmc_traffic_base_b512.json')
+    """(HBM bytes per launch of the dominant kernel, where that number comes from).  Counters cannot be read from inside the
+    process: the value is the one the committed rocprofv3 --pmc passes measured on this command line (tools/pmc_bench.sh:
+    2 x FETCH_SIZE per the gfx950 calibration + WRITE_SIZE) -- reported only while the kernel sources are the ones profiled."""
+    if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512):
+        return None, 'none: not the profiled workload'
+    name = 'r02_pmc_base_b512.json' if args.objective == 'supervised' else 'r02_pmc_base_b512_masked.json'
+    path = os.path.join(ROOT, 'profiles', name)
     try:
         with open(path) as f:
-            return json.load(f)[kernel_key]['hbm_bytes_per_launch']
+            prof = json.load(f)
     except Exception:
-        return None
+        return None, f'none: profiles/{name} not found'
+    if prof.get('kernel_source_sha16') != kernel_source_hash():
+        return None, f'none: kernel sources changed since profiles/{name} (taken on sources {prof.get("kernel_source_sha16")})'
+    try:
+        return prof['kernels'][kernel_key]['hbm_bytes_per_launch'], f'profiles/{name} @ sources {prof["kernel_source_sha16"]}'
+    except KeyError:
+        return None, f'none: profiles/{name} has no entry for {kernel_key}'
 
 
 def cpu_baseline(conf, seconds_budget=25.0, masked=False):
     """the CPU oracle (torch eager f32 restatement of the reference step) on the host cores, bounded sample (~seconds_budget)"""
-    from oracle import vit_oracle as O
+    from oracle import vit_oracle as O   # the ONLY place bench.py touches the oracle: the timed CPU baseline
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -175,6 +201,8 @@ def main():
                     help="'supervised' = the reference's BCE step; 'masked' = the build's SimMIM-style masked pre-train step (seq = n patches, no CLS)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
+    ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
+    ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -189,29 +217,11 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import ecg_representation_learning_amd as E
-    from oracle import vit_oracle as O  # only: synthetic_batch helper + FLOP formula + the cpu_baseline leg
     E.hip.lib()  # fail loudly if the HIP library is missing
 
     conf, batch = make_config(E, args.config, args.patch, args.length, args.dropout)
     batch = args.batch or batch
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    torch.manual_seed(77)  # identical initial weights on every rank
-    model = E.EcgVit(config=conf, compute_dtype=dtype)
-    if args.objective == 'masked':
-        model = E.MaskedEcgVit(model, mask_ratio=0.5)
-    model = model.to(dev).train()
-    x, y = O.synthetic_batch(batch, length=conf.max_signal_length, seed=77 + rank)
-    x, y = x.to(dev), y.to(dev)
-    if args.objective == 'masked':
-        y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank)).to(dev)   # (B, m) int32
-    n_total = args.steps + args.warmup
-    step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total))
-    run_step = step.step_masked if args.objective == 'masked' else step.step
-
-    probe = None
-    if not args.no_probe and dtype == torch.bfloat16:
-        probe = GemmProbe(E.hip, E.hip.GEMM_NT, torch.bfloat16)
-        probe.install()
 
     def sync():
         if world > 1:
@@ -219,28 +229,76 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run_step(x, y)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
+    def timed_run(objective, steps, warmup):
+        """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result)"""
+        torch.manual_seed(77)  # identical initial weights on every rank (HipTrainStep broadcasts rank 0's anyway)
+        model = E.EcgVit(config=conf, compute_dtype=dtype)
+        if objective == 'masked':
+            model = E.MaskedEcgVit(model, mask_ratio=0.5)
+        model = model.to(dev).train()
+        x, y = E.workload.synthetic_batch(batch, length=conf.max_signal_length, seed=77 + rank)
+        x, y = x.to(dev), y.to(dev)
+        if objective == 'masked':
+            y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank)).to(dev)   # (B, m) int32
+        n_total = steps + warmup
+        step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total),
+                              sync_nonfinite=not args.defer_nonfinite)
+        run_step = step.step_masked if objective == 'masked' else step.step
+        probe = None
+        if not args.no_probe and dtype == torch.bfloat16:
+            probe = GemmProbe(E.hip, E.hip.GEMM_NT, torch.bfloat16)
+            probe.install()
+        for _ in range(warmup):
+            run_step(x, y)
+        sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if probe:
+                probe.enabled = rank == 0 and i % 4 == 0   # HIP events around the dominant kernel's launches on every 4th timed step
+            loss, _ = run_step(x, y)                      # (192 event records per probed step cost ~0.7 % when taken on every step)
+        sync()
+        dt = time.perf_counter() - t0
         if probe:
-            probe.enabled = rank == 0 and i % 4 == 0   # HIP events around the dominant kernel's launches on every 4th timed step
-        loss, _ = run_step(x, y)                      # (192 event records per probed step cost ~0.7 % when taken on every step)
-    sync()
-    dt = time.perf_counter() - t0
-    if probe:
-        probe.enabled = False
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss)
-    step.finish()
+            probe.enabled = False
+            probe.uninstall()
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        final_loss = float(loss)
+        step.finish()
+        return dt, final_loss, (probe.result() if probe else None)
+
+    def roofline_of(r, objective):
+        if not r:
+            return None
+        margs = argparse.Namespace(**{**vars(args), 'objective': objective})
+        traffic, source = pmc_traffic('gemm_nt', margs)
+        return {
+            'kernel': 'gemm_nt_kernel<bf16 out> (persistent quadrant-phased 256x256x64 LDS-DMA GEMM with a register-direct epilogue, A . B^T: '
+                      'the Linear forward launches QKV / attn-out / FFN-up / FFN-down and, against the transposed weight shadows, their input-gradient launches)',
+            'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
+            'traffic': traffic, 'traffic_source': source, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
+            'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
+        }
+
+    dt, final_loss, pres = timed_run(args.objective, args.steps, args.warmup)
+    masked_line = None
+    if args.objective == 'supervised' and world == 1 and args.config == 'base' and not args.no_masked:
+        # the build's own masked pre-train objective (absent from the reference: SURVEY 0), driver-timed next to the headline step
+        msteps = min(args.steps, 20)
+        mdt, mloss, mres = timed_run('masked', msteps, min(args.warmup, 3))
+        n_patch = conf.max_signal_length // conf.patch_size
+        masked_line = {
+            'workload': f'EcgVit-{args.config} masked-patch pre-train step (SimMIM-style: 50 % of the {n_patch} patches replaced by a mask token, no CLS, '
+                        f'L1 reconstruction of the masked patches; fwd+loss+bwd+clip+AdamW), dropout {conf.hidden_dropout_prob}, {batch} records/GPU',
+            'value': batch * msteps / mdt, 'unit': 'records/s', 'steps': msteps, 'ms_per_step': 1e3 * mdt / msteps, 'final_loss': mloss,
+            'roofline': roofline_of(mres, 'masked'),
+        }
 
     if rank == 0:
-        flops_rec = O.train_flops_per_record(conf)
+        flops_rec = E.workload.train_flops_per_record(conf)
         value = batch * world * args.steps / dt
         out = {
             'metric': '12-lead ECG records/sec pre-train step, ViT-Base bf16 @ 1/2/4/8 MI355X' if args.config == 'base'
@@ -261,16 +319,10 @@ def main():
             'model_tflops_per_gpu': value / world * flops_rec / 1e12,
             'mfma_frac_of_peak': value / world * flops_rec / 1e12 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS),
         }
-        if probe:
-            r = probe.result()
-            if r:
-                out['roofline'] = {
-                    'kernel': 'gemm_bf16_q_kernel<bf16 out> (persistent quadrant-phased 256x256x64 LDS-DMA GEMM, A . B^T: the Linear forward '
-                              'launches QKV / attn-out / FFN-up / FFN-down and, against the transposed weight shadows, their input-gradient launches)',
-                    'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
-                    'traffic': pmc_traffic('gemm_q', args), 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
-                    'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
-                }
+        if pres:
+            out['roofline'] = roofline_of(pres, args.objective)
+        if masked_line:
+            out['masked'] = masked_line
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(conf, masked=args.objective == 'masked')
         print(json.dumps(out), flush=True)

@@ -13,6 +13,7 @@ from .metrics import get_accuracy, eval_counts, HipEvaluator
 from .feed import DeviceFeeder, ptbxl_splits, lbs2multi_hot, open_records
 from . import hip
 from . import ddp
+from . import workload
 
 __all__ = ['ca', 'CheckArg', 'EcgVitConfig', 'EcgVit', 'ModelOutput', 'HipViT', 'MaskedEcgVit', 'load_trained', 'get_train_args', 'lr_multiplier',
-           'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'get_accuracy', 'eval_counts', 'HipEvaluator', 'DeviceFeeder', 'ptbxl_splits', 'lbs2multi_hot', 'open_records', 'hip', 'ddp']
+           'HipTrainStep', 'clip_grad_norm_', 'FusedInputTransform', 'get_accuracy', 'eval_counts', 'HipEvaluator', 'DeviceFeeder', 'ptbxl_splits', 'lbs2multi_hot', 'open_records', 'hip', 'ddp', 'workload']

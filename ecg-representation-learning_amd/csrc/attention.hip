@@ -905,35 +905,44 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
     return ECGVIT_OK;
 }
 
-int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
-                         int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
-    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) % 16) return ECGVIT_EINVAL;
+static int attention_bwd_args_ok(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int N, int h, int dh, int dtype) {
+    if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return 0;
+    return (reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(dqkv)) % 16 == 0;
+}
+
+// one (record, head) item per workgroup, all keys of the item on its waves: N <= 256 only.  The shipped backward for short
+// sequences (N <= 128) and the independent implementation the tests hold the persistent kernel against.
+int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                                 int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype) || N > 256) return ECGVIT_EINVAL;
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     dim3 grid((unsigned)(B * h));
-    static const int ablate = [] { const char *e = getenv("ECGVIT_ATTN_ABLATE"); return e ? atoi(e) : 0; }();   // diagnostics only
-    const char *pe = getenv("ECGVIT_ATTN_PERSIST");   // read per call: tests compare both kernels in one process
-    const bool pers = !(pe && pe[0] == '0');
-    if (pers && N > 128 && !ablate && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31)) {
-        const int nitems = B * h;
-        const dim3 pg((unsigned)(nitems < 256 ? nitems : 256));
-#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0)
-        if (th) PERS(true, false, 0); else PERS(false, false, 0);
-        ECGVIT_CHECK_LAUNCH();
-        if (N > 256) {   // second window of keys; its dQ accumulates on the first launch's (stream order)
-            if (th) PERS(true, true, 256); else PERS(false, true, 256);
-            ECGVIT_CHECK_LAUNCH();
-        }
-#undef PERS
-        return ECGVIT_OK;
-    }
-    if (N > 256) return ECGVIT_EINVAL;   // the one-item kernels hold all keys of a record-head on 8 waves
-#define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, ablate)
+#define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, 0)
     if (N <= 128) { if (th) BWD(4, true); else BWD(4, false); }
     else { if (th) BWD(8, true); else BWD(8, false); }
 #undef BWD
     ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                         int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype)) return ECGVIT_EINVAL;
+    if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31))   // short sequences / 32-bit buffer offsets exhausted
+        return ecgvit_attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const int nitems = B * h;
+    const dim3 pg((unsigned)(nitems < 256 ? nitems : 256));
+#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0)
+    if (th) PERS(true, false, 0); else PERS(false, false, 0);
+    ECGVIT_CHECK_LAUNCH();
+    if (N > 256) {   // second window of keys; its dQ accumulates on the first launch's (stream order)
+        if (th) PERS(true, true, 256); else PERS(false, true, 256);
+        ECGVIT_CHECK_LAUNCH();
+    }
+#undef PERS
     return ECGVIT_OK;
 }
 

@@ -300,25 +300,19 @@ inline int choose_splits(const ecgvit_gemm_desc *d, int ntile) {
 
 }  // namespace
 
-// large-shape variant (gemm_bf16_v2.hip)
-bool ecgvit_gemm_bf16_v2_applicable(const ecgvit_gemm_desc *d);
-int64_t ecgvit_gemm_bf16_v2_workspace(const ecgvit_gemm_desc *d);
-int ecgvit_gemm_bf16_v2_launch(const ecgvit_gemm_desc *d, hipStream_t s);
-// large A . B^T products (gemm_nt.hip)
+// large weight-gradient products (gemm_wgrad.hip) and large A . B^T products (gemm_nt.hip)
+bool ecgvit_gemm_wgrad_applicable(const ecgvit_gemm_desc *d);
+int64_t ecgvit_gemm_wgrad_workspace(const ecgvit_gemm_desc *d);
+int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s);
 bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);
-
-static bool use_v2() {
-    static const bool on = [] { const char *e = getenv("ECGVIT_GEMM_V2"); return !(e && e[0] == '0'); }();
-    return on;
-}
 
 extern "C" int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d) {
     if (d->dtype != ECGVIT_BF16 || d->layout != ECGVIT_GEMM_TN) return 0;
     const int ntile = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
     const int s = choose_splits(d, ntile);
     const int64_t v1 = s > 1 ? (int64_t)s * d->M * d->N * 4 : 0;
-    return std::max(v1, ecgvit_gemm_bf16_v2_workspace(d));
+    return std::max(v1, ecgvit_gemm_wgrad_workspace(d));
 }
 
 int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
@@ -338,7 +332,7 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
     if (ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, s, 0, 0);
-    if (use_v2() && ecgvit_gemm_bf16_v2_applicable(d)) return ecgvit_gemm_bf16_v2_launch(d, s);
+    if (ecgvit_gemm_wgrad_applicable(d)) return ecgvit_gemm_wgrad_launch(d, s);
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     SplitK sk;
     sk.splits = 1;
@@ -381,8 +375,7 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     if (!d) return ECGVIT_EINVAL;
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
-        if (d->dtype == ECGVIT_BF16 && (ecgvit_gemm_nt_applicable(d) || (use_v2() && ecgvit_gemm_bf16_v2_applicable(d))))
-            return ecgvit_gemm_bf16_launch(d, as_stream(stream));
+        if (d->dtype == ECGVIT_BF16 && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream));   // fused column sums
         // generic path: plain GEMM, then the stand-alone column-sum kernel over the stored output
         if (d->workspace_bytes < ecgvit_colsum_workspace(d->M, d->N)) return ECGVIT_EINVAL;
         ecgvit_gemm_desc g = *d;
@@ -397,12 +390,10 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
 }
 
 #ifdef ECGVIT_TOOLS
-// tools build only (libecgvit_hip_tools.so): pick the kernel behind one A . B^T call, for A/B timing inside one process.
-// kernel: 0 = the shipped dispatch, 1 = the retired LDS-patch kernel, 2 = gemm_nt_kernel with column groups of raster_g n-tiles
-// (0 = built-in choice) and diag bits (1 = stamped build, 2 = stores dropped)
+// tools build only (libecgvit_hip_tools.so): one A . B^T call on gemm_nt_kernel with column groups of raster_g n-tiles (0 = the
+// built-in order) and diag bits (1 = stamped instantiation, 2 = its output stores dropped): tools/gemm_ab.py, tools/nt_stamps.py
 extern "C" int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g, int diag) {
     if (!d) return ECGVIT_EINVAL;
-    if (kernel == 1) return ecgvit_gemm_bf16_v2_applicable(d) ? ecgvit_gemm_bf16_v2_launch(d, as_stream(stream)) : ECGVIT_EINVAL;
     if (kernel == 2) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt_launch(d, as_stream(stream), raster_g, diag) : ECGVIT_EINVAL;
     return ecgvit_gemm(d, stream);
 }

@@ -511,7 +511,7 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     return true;
 }
 
-void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s);   // gemm_bf16_v2.hip
+void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s);   // gemm_wgrad.hip
 
 // argument validation is done by the caller (ecgvit_gemm_bf16_launch); raster_g <= 0 selects the built-in choice
 int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {

@@ -196,6 +196,9 @@ class _EcgVitFunction(torch.autograd.Function):
                                '(one live graph per model; call backward before the next forward)')
         eng = model._engine()
         B, K = eng.saved['B'], eng.K
+        if (gloss is None or not ctx.has_labels) and glogits is None:
+            return (None,) * (5 + len(model._own_list))
+        keep, aliased = _grads_living_in_flat_buffer(model, model._own_names, model._own_list)
         if gloss is not None and ctx.has_labels:
             if glogits is not None:
                 raise NotImplementedError('gradients through both loss and logits of one forward')
@@ -203,12 +206,34 @@ class _EcgVitFunction(torch.autograd.Function):
                 eng.backward(gscalar=gloss.contiguous().float(), gscale=1.0 / (B * K))
             else:
                 eng.backward(gelem=gloss.contiguous().float(), gscale=1.0)
-        elif glogits is not None:
-            eng.backward(glogits=glogits.contiguous().float())
         else:
-            return (None,) * (5 + len(model._own_list))
-        grads = tuple(model._layout.view(model._gflat, n) for n in model._own_names)
-        return (None, None, None, None, None) + grads
+            eng.backward(glogits=glogits.contiguous().float())
+        return (None, None, None, None, None) + _grads_out(model, model._own_names, keep, aliased)
+
+
+def _grads_living_in_flat_buffer(model, names, params):
+    """Parameters whose `.grad` IS a view of the engine's flat gradient buffer (AccumulateGrad adopted the views a previous backward
+    returned).  The engine overwrites that buffer, so an accumulating backward (`zero_grad(set_to_none=False)`, gradient accumulation
+    over micro-batches) would otherwise compute `p.grad += p.grad`-of-the-new-values: keep a copy of the old contents to add back.
+    Returns (copy of the flat buffer or None, set of aliased names)."""
+    g = model._gflat
+    aliased = {n for n, p in zip(names, params)
+               if p.grad is not None and p.grad.data_ptr() == g.data_ptr() + 4 * model._layout.entries[n][0]}
+    return (g.clone() if aliased else None), aliased
+
+
+def _grads_out(model, names, keep, aliased):
+    """gradient tuple for autograd: aliased parameters were accumulated in place (old + new) and return None; the others return their
+    view of the flat buffer (adopted as `.grad` when it was None, added to a foreign `.grad` otherwise)"""
+    out = []
+    for n in names:
+        v = model._layout.view(model._gflat, n)
+        if n in aliased:
+            v.add_(model._layout.view(keep, n))
+            out.append(None)
+        else:
+            out.append(v)
+    return tuple(out)
 
 
 class EcgVit(nn.Module):
@@ -442,8 +467,9 @@ class _MaskedFunction(torch.autograd.Function):
             raise NotImplementedError('gradients through the reconstruction output')
         if gloss is None:
             return (None,) * (3 + len(enc._param_list))
+        keep, aliased = _grads_living_in_flat_buffer(enc, enc._param_names, enc._param_list)
         enc._engine().backward_masked(gscalar=gloss.contiguous().float().reshape(1))
-        return (None, None, None) + tuple(enc._layout.view(enc._gflat, n) for n in enc._param_names)
+        return (None, None, None) + _grads_out(enc, enc._param_names, keep, aliased)
 
 
 class MaskedEcgVit(nn.Module):
@@ -474,10 +500,25 @@ class MaskedEcgVit(nn.Module):
         """(B, m) int32 on the host: per record, the first m entries of a random permutation of the n patches"""
         return torch.stack([torch.randperm(self.n_patch, generator=generator)[:self.n_mask] for _ in range(batch)]).to(torch.int32)
 
+    def check_mask_indices(self, mask_idx, batch):
+        """(B, m) integer tensor of DISTINCT patch indices in [0, n_patch) per record, else ValueError: the row gather / scatter
+        kernels index with them unchecked (an out-of-range index is an out-of-bounds access, a duplicate a racy scatter)"""
+        if mask_idx.dim() != 2 or mask_idx.shape[0] != batch or not 0 < mask_idx.shape[1] <= self.n_patch:
+            raise ValueError(f'mask_idx must be (batch={batch}, m) with 0 < m <= {self.n_patch}, got {tuple(mask_idx.shape)}')
+        if mask_idx.dtype.is_floating_point or mask_idx.dtype == torch.bool:
+            raise ValueError(f'mask_idx must be an integer tensor, got {mask_idx.dtype}')
+        idx = mask_idx.to(torch.int64)
+        if int(idx.min()) < 0 or int(idx.max()) >= self.n_patch:
+            raise ValueError(f'mask_idx entries must lie in [0, {self.n_patch})')
+        srt = torch.sort(idx, dim=1).values
+        if bool((srt[:, 1:] == srt[:, :-1]).any()):
+            raise ValueError('mask_idx holds a duplicate patch index inside a record')
+
     def forward(self, sample_values, mask_idx):
         if not sample_values.is_cuda:
             raise RuntimeError('MaskedEcgVit (HIP) runs on an MI355X device only (no CPU fallback)')
         x = sample_values.contiguous().float()
+        self.check_mask_indices(mask_idx, x.shape[0])
         idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
         loss, pred = _MaskedFunction.apply(self, x, idx, *self.encoder._param_list)
         return ModelOutput(loss=loss, logits=pred)

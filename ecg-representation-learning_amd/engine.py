@@ -25,10 +25,10 @@ def _align(n, a=8):
     return (n + a - 1) // a * a
 
 
-_DGRAD_T = os.environ.get('ECGVIT_DGRAD_T', '1') != '0'   # experiments: 0 = input gradients on the A.B kernel
-# 256 < N <= 512 tokens: the fused persistent backward runs as two key windows; 1 = the exact-f32 recompute fallback instead (A/B, and the
-# only way when ECGVIT_ATTN_PERSIST=0)
-_LONG_FALLBACK = os.environ.get('ECGVIT_ATTN_LONG_FALLBACK', '0') == '1' or os.environ.get('ECGVIT_ATTN_PERSIST', '1') == '0'
+# 256 < N <= 512 tokens: the fused persistent attention backward runs as two key windows.  True = recompute the probabilities with the
+# exact-f32 batched kernels of the parity path instead (a slower, independent route kept for cross-checks: set it on the module
+# before the engine allocates).
+_LONG_FALLBACK = False
 
 
 class ParamLayout:
@@ -153,7 +153,7 @@ class VitEngine:
     def _dgrad(self, dY, name, dX, M, kin, nout, **kw):
         """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one"""
         wt = self.WT.get(name)
-        if wt is not None and M >= 2048 and _DGRAD_T:
+        if wt is not None and M >= 2048:
             hip.gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
         else:
             hip.gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
@@ -332,7 +332,7 @@ class VitEngine:
         d, n = self.d, self.n
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
-        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m)
+        self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m, training=training)
         self._patch_embed(x, B)
         check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),
                                          ptr(idx), ptr(a['x0']), ptr(a['flag']), B, n, m, d, T, st), 'mask_embed_finish')

@@ -67,8 +67,8 @@ class DeviceFeeder:
 
     Double-buffered: while the step consumes batch i, a worker thread gathers batch i+1 from the (memory-mapped) store into pinned
     memory (float64 -> float32 as the reference's `__getitem__` does) and queues its H2D copy on a side stream; the consumer's stream
-    waits on the copy's event only.  `shuffle` permutes with `torch.randperm` per epoch (seeded); `rank/world` take a contiguous
-    shard of every epoch's order (`ddp.shard_range` semantics).  On a CPU-only host (tests) it degrades to synchronous host tensors.
+    waits on the copy's event only.  `shuffle` permutes with `torch.randperm` per epoch (seeded); `rank/world` take a contiguous,
+    equally long shard of every epoch's order (wrapped around when n is not a multiple of the world size).  On a CPU-only host (tests) it degrades to synchronous host tensors.
     """
 
     def __init__(self, records, idxs, labels_multi_hot, batch_size, shuffle=False, seed=77, device=None, rank=0, world=1,
@@ -89,9 +89,11 @@ class DeviceFeeder:
         return n // self.bsz if self.drop_last else (n + self.bsz - 1) // self.bsz
 
     def _shard_len(self):
+        """records per rank and epoch: EQUAL on every rank (ceil(n / world), the epoch's order wraps around to fill the last shard, as
+        torch's DistributedSampler pads), so that every rank yields the same number of batches of the same sizes -- the train step's
+        gradient all-reduce is collective, a rank with one batch fewer would hang the others"""
         n = len(self.idxs)
-        lo, hi = (self.rank * n) // self.world, ((self.rank + 1) * n) // self.world
-        return hi - lo
+        return (n + self.world - 1) // self.world
 
     def _order(self):
         n = len(self.idxs)
@@ -100,8 +102,10 @@ class DeviceFeeder:
             perm = torch.randperm(n, generator=g).numpy()
         else:
             perm = np.arange(n)
-        lo, hi = (self.rank * n) // self.world, ((self.rank + 1) * n) // self.world
-        return perm[lo:hi]
+        per = self._shard_len()
+        if per * self.world > n:
+            perm = np.concatenate([perm, perm[:per * self.world - n]])
+        return perm[self.rank * per:(self.rank + 1) * per]
 
     def _gather(self, rows, x_buf, y_buf):
         b = len(rows)

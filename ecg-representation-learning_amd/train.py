@@ -7,11 +7,14 @@ Mirrors `ecg_transformer/models/train.py`:
   the step body (:268-283): zero_grad -> forward -> backward -> clip_grad_norm_(1.0, error_if_nonfinite) -> AdamW -> sched
 
 `HipTrainStep` runs that body fused on flat HBM buffers: one sum-of-squares pass over the flat gradient, one
-clip+AdamW pass that also refreshes the bf16 weight shadow, no per-parameter launches and no host sync in the step
-(the non-finite check of `error_if_nonfinite=True` is evaluated one step late from a device flag, or immediately with
-`sync_nonfinite=True`).  Data parallel (reference has none): one process per GPU, gradients all-reduced over
-RCCL in per-layer buckets of the flat gradient buffer (28 MB f32 each for base), each launched asynchronously the moment the
-backward pass has finished that layer (head, layers L-1..0, embedding), so the exchange overlaps the remaining backward.
+clip+AdamW pass that also refreshes the bf16 weight shadow, no per-parameter launches.  `error_if_nonfinite=True` is
+honoured in the SAME step, as the reference does (train.py:281): the kernel skips the whole update on a non-finite norm and
+the step reads the flag back before it returns (`sync_nonfinite=False` defers that read by one step to keep the host running
+ahead of the device).  Data parallel (reference has none): one process per GPU; the replicas are made identical
+once (broadcast of rank 0's flat parameter buffer), every rank draws its own dropout masks (rank folded into the seed), and
+gradients are all-reduced over RCCL in per-layer buckets of the flat gradient buffer (28 MB f32 / 14 MB bf16 each for base),
+each launched asynchronously the moment the backward pass has finished that layer (head, layers L-1..0, embedding), so the
+exchange overlaps the remaining backward.
 
 Logging / TensorBoard / sklearn metrics / datasets of MyTrainer are host-side and out of scope here.
 """
@@ -77,7 +80,10 @@ class HipTrainStep:
     args: dict as produced by `get_train_args` (uses optimizer, learning_rate, weight_decay, warmup_ratio, schedule, n_step).
     """
 
-    def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=False, process_group=None, overlap_allreduce=True):
+    def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=True, process_group=None, overlap_allreduce=True,
+                 grad_comm_dtype=torch.float32):
+        """grad_comm_dtype: torch.float32 (exact exchange) or torch.bfloat16 (each bucket is cast to bf16, all-reduced at half the
+        bytes over xGMI and added back into the f32 gradient buffer; the optimiser still sees f32)"""
         self.model = model
         self.args = {**get_train_args(), **(args or dict())}
         ca(optimizer=self.args['optimizer'], schedule=self.args['schedule'])
@@ -93,8 +99,13 @@ class HipTrainStep:
         self.last_loss = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         self.overlap = overlap_allreduce
-        self._works, self._launched, self._bucket_ranges, self._bucket_names = [], set(), {}, []
+        if grad_comm_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('grad_comm_dtype must be torch.float32 or torch.bfloat16')
+        self.comm_dtype = grad_comm_dtype
+        self._xchg = self._xchg_layout = None
+        self._replicas_synced = False
 
     # -- lr as the reference logs it: scheduler.get_last_lr() after `step_count` scheduler steps
     def get_last_lr(self):
@@ -111,39 +122,32 @@ class HipTrainStep:
             self._flag_event = torch.cuda.Event()
             self.sumsq = torch.zeros(1, device=m._pflat.device, dtype=torch.float32)
             self.ws = torch.empty(hip.lib().ecgvit_sumsq_workspace(m._pflat.numel()), device=m._pflat.device, dtype=torch.uint8)
+            self._replicas_synced = False
+        if self.world > 1 and not self._replicas_synced:
+            # data-parallel replicas must start from the same weights whatever each rank's RNG produced: rank 0's flat buffer wins
+            ddp.broadcast_flat_(m._pflat, src=0, group=self.pg)
+            if m._wlow is not None:
+                m.refresh_low_precision_weights(force=True)
+            self._replicas_synced = True
 
-    # -- gradient all-reduce (RCCL over xGMI): one collective over the flat gradient buffer
-    def _allreduce(self, gflat):
-        """N > 1: finish the gradient exchange. With overlap on, every bucket was already launched (async, on RCCL's own stream)
-        by `_bucket_ready` the moment the backward pass completed it; here we only wait for them."""
-        if self.world == 1:
-            return
-        if self.overlap:
-            for w in self._works:
-                w.wait()
-            self._works = []
-            missing = set(self._bucket_names) - self._launched
-            assert not missing, f'gradient buckets never reported ready: {missing}'
-        else:
-            ddp.allreduce_flat_(gflat, group=self.pg)
+    def _dropout_seed(self, model):
+        """one fresh seed per step from the host RNG; the rank is folded in so that replicas seeded identically (as DDP scripts
+        do) still drop different units of their different records"""
+        if not model._has_dropout:
+            return 0
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return (base + 0x3C6EF35F * self.rank) % (2 ** 31 - 1)
 
-    def _bucket_ready(self, tag):
-        """engine callback: the gradients of bucket `tag` are final -> start their all-reduce now, overlapped with the rest of
-        the backward pass (reverse-layer order: head, layers L-1..0, embedding)"""
-        if self.world == 1 or not self.overlap or tag not in self._bucket_ranges or tag in self._launched:
-            return
-        lo, hi = self._bucket_ranges[tag]
-        self._launched.add(tag)
-        self._works.append(dist.all_reduce(self._gflat_ref[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-
+    # -- gradient all-reduce (RCCL over xGMI): ddp.GradExchange over the flat gradient buffer
     def _arm_overlap(self, model):
         eng = model._engine()
-        if self.world > 1 and self.overlap:
-            rng = dict(model._layout.buckets_in_ready_order(eng.Ly))
-            self._bucket_ranges, self._bucket_names = rng, list(rng)
-            self._gflat_ref = model._gflat
-            self._launched, self._works = set(), []
-            eng.on_grads_ready = self._bucket_ready
+        if self.world > 1:
+            if self._xchg is None or self._xchg_layout is not model._layout:
+                self._xchg = ddp.GradExchange(model._layout.buckets_in_ready_order(eng.Ly), group=self.pg, overlap=self.overlap,
+                                              comm_dtype=self.comm_dtype)
+                self._xchg_layout = model._layout
+            self._xchg.begin(model._gflat)
+            eng.on_grads_ready = self._xchg.bucket_ready if self.overlap else None
         else:
             eng.on_grads_ready = None
 
@@ -155,20 +159,23 @@ class HipTrainStep:
         self._state()
         self._raise_if_flagged()
         eng = model._engine()
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model._has_dropout else 0
+        seed = self._dropout_seed(model)
         x = sample_values.contiguous().float()
+        wrapper.check_mask_indices(mask_idx, x.shape[0])
         idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
         pred, loss = eng.forward_masked(x, idx, training=True, seed=seed)
         model._fwd_id += 1
         self._arm_overlap(model)
         eng.backward_masked()
+        loss, pred = loss.clone(), pred.clone()   # the engine reuses its buffers next step: hand out copies
         self._update(model)
         self.last_loss = loss
         return loss, pred
 
     def _update(self, model):
         gflat = model._gflat
-        self._allreduce(gflat)
+        if self.world > 1:
+            self._xchg.finish()
         l = hip.lib()
         st = hip.stream()
         hip.check(l.ecgvit_sumsq(gflat.data_ptr(), gflat.numel(), self.sumsq.data_ptr(), self.ws.data_ptr(), st), 'sumsq')
@@ -194,7 +201,7 @@ class HipTrainStep:
         self._state()
         self._raise_if_flagged()
         eng = model._engine()
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if model._has_dropout else 0
+        seed = self._dropout_seed(model)
         x = sample_values.contiguous().float()
         y = labels.contiguous().float()
         w = None
@@ -205,6 +212,7 @@ class HipTrainStep:
         B, K = x.shape[0], eng.K
         self._arm_overlap(model)
         eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
+        loss_mean, logits = loss_mean.clone(), logits.clone()   # the engine reuses its buffers next step: hand out copies
         self._update(model)
         self.last_loss = loss_mean
         return loss_mean, logits

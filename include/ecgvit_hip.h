@@ -149,6 +149,11 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
 int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
                          int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
                          void *stream);
+/* The same backward on the one-(record, head)-per-workgroup kernel (N <= 256; what ecgvit_attention_bwd itself runs for N <= 128):
+ * an independent implementation of the same function, exported so that tests can hold the persistent kernel against it. */
+int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                                 int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
+                                 void *stream);
 /* export of the fused path's post-softmax probabilities (next row f3; what vit_pytorch's Recorder hooks, reference ecg_vit.py:176-180):
  * probs[B,h,N,N] f32 = exp(scale * q k^T - lse), from the qkv / lse a fused forward left behind. bf16 path only (the f32 path
  * materialises the scores anyway); visualisation-time, not tuned. B*h <= 65535. */

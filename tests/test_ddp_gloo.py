@@ -48,11 +48,24 @@ def _worker(rank, world, port, out_dir):
     gflat = torch.zeros(layout.total)
     for n, p in model.named_parameters():
         layout.view(gflat, n).copy_(p.grad)
+    # the train step's exchange object: per-layer buckets launched in backward order (overlap), f32 and bf16 on the wire
+    local = gflat.clone()
+    xout = {}
+    for tag, kw in (('f32_overlap', dict(overlap=True)), ('f32_single', dict(overlap=False)),
+                    ('bf16_overlap', dict(overlap=True, comm_dtype=torch.bfloat16)), ('bf16_single', dict(overlap=False, comm_dtype=torch.bfloat16))):
+        g2 = local.clone()
+        ranges = layout.buckets_in_ready_order(cfg.num_hidden_layers)
+        ex = E.ddp.GradExchange(ranges, **kw)
+        ex.begin(g2)
+        for name, _ in ranges:
+            ex.bucket_ready(name)
+        ex.finish()
+        xout[tag] = g2 / ex.world
     w = E.ddp.allreduce_flat_(gflat, bucket_elems=1000 if rank >= 0 else 0)   # bucketed variant
     gflat /= w
     norm = gflat.norm()
     coef = torch.clamp(1.0 / (norm + 1e-6), max=1.0)
-    torch.save(dict(g=gflat * coef, norm=norm, loss=out.loss.detach(), p=pflat.clone(), seed=E.ddp.rank_seed(77, rank)),
+    torch.save(dict(g=gflat * coef, norm=norm, loss=out.loss.detach(), p=pflat.clone(), seed=E.ddp.rank_seed(77, rank), xchg=xout, gavg=gflat.clone()),
                os.path.join(out_dir, f'rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -66,6 +79,13 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
     assert torch.equal(r0['p'], r1['p'])                       # broadcast made the replicas identical
     assert torch.allclose(r0['g'], r1['g'], rtol=0, atol=0)    # every rank holds the same reduced, clipped gradient
     assert (r0['seed'], r1['seed']) == (77, 78)
+    # GradExchange: the f32 forms equal the plain all-reduce bit for bit; bf16 on the wire stays within bf16 rounding of it
+    for tag in ('f32_overlap', 'f32_single'):
+        assert torch.equal(r0['xchg'][tag], r0['gavg']) and torch.equal(r1['xchg'][tag], r0['gavg'])
+    for tag in ('bf16_overlap', 'bf16_single'):
+        assert torch.equal(r0['xchg'][tag], r1['xchg'][tag])
+        rel = float((r0['xchg'][tag] - r0['gavg']).norm() / r0['gavg'].norm())
+        assert 0 < rel < 8e-3, rel          # tolerance: 2 ranks x bf16 (8 significant bits) contributions, bf16 sum
     # single-process full-batch reference
     from ecg_representation_learning_amd.engine import ParamLayout
     from oracle import vit_oracle as O

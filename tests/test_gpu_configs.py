@@ -1,0 +1,148 @@
+"""-m gpu: the BASELINE.json configurations themselves.
+
+  (a) EcgVit-base and EcgVit-small LAYER SHAPES (d=768/h=12/f=3072 and d=512/h=8/f=2048, 12 x 5000 samples, patch 20 -> 251 tokens,
+      2 layers, 8 records) against the CPU ORACLE directly -- the f32 HIP path within the north_star's 1e-4 relative, the bf16 HIP
+      path within bf16 rounding (loss <= 2e-2 relative, gradient cosine >= 0.98);
+  (b) the FULL configurations (base: 12 layers, 512 records; small: 8 layers, 256 records; bf16, dropout 0.1 as benchmarked) through
+      size-independent properties: finite outputs, bit-identical rerun under a pinned seed, batch-slice invariance in eval, a
+      falling loss over three fused train steps;
+  (c) host-contract regressions found by review: gradient accumulation through the autograd surface, copies handed out by the
+      fused step, mask-index validation.
+"""
+import pytest
+import torch
+
+from hiputil import rel_err, max_err
+from oracle import vit_oracle as O
+import ecg_representation_learning_amd as E
+
+pytestmark = pytest.mark.gpu
+F32, BF16 = torch.float32, torch.bfloat16
+
+SHAPES = {
+    'base': dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072),
+    'small': dict(hidden_size=512, num_attention_heads=8, intermediate_size=2048),
+}
+
+
+def _pair(name, layers, B, dtype, seed=77):
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, num_hidden_layers=layers, hidden_dropout_prob=0., attention_probs_dropout_prob=0.,
+                          **SHAPES[name])
+    torch.manual_seed(seed)
+    ref = O.OracleEcgVit(config=conf).train()
+    m = E.EcgVit(config=conf, compute_dtype=dtype)
+    m.load_state_dict(ref.state_dict())
+    x, y = O.synthetic_batch(B, length=5000, seed=seed)
+    return ref, m.cuda().train(), x, y
+
+
+@pytest.mark.parametrize('name', ['base', 'small'])
+def test_layer_shape_f32_and_bf16_vs_cpu_oracle(name):
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    ref, m32, x, y = _pair(name, 2, 8, F32)
+    o_ref = ref(sample_values=x, labels=y)
+    o_ref.loss.backward()
+    gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+    xc, yc = x.cuda(), y.cuda()
+    # f32 HIP path: north_star tolerance, 1e-4 relative
+    out = m32(sample_values=xc, labels=yc)
+    out.loss.backward()
+    assert abs(float(out.loss) - float(o_ref.loss)) / float(o_ref.loss) < 1e-4
+    assert max_err(out.logits, o_ref.logits) < 1e-4
+    for (k, p), (_, q) in zip(m32.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 1e-4, (k, rel_err(p.grad, q.grad))
+    # bf16 HIP path: bf16 storage of activations / weight shadows, f32 accumulate
+    m16 = E.EcgVit(config=m32.config, compute_dtype=BF16)
+    m16.load_state_dict(ref.state_dict())
+    m16.cuda().train()
+    o16 = m16(sample_values=xc, labels=yc)
+    o16.loss.backward()
+    assert abs(float(o16.loss) - float(o_ref.loss)) / float(o_ref.loss) < 2e-2
+    assert max_err(o16.logits, o_ref.logits) < 0.15
+    g16 = torch.cat([p.grad.flatten() for p in m16.parameters()]).double().cpu()
+    cos = float((g16 @ gref) / (g16.norm() * gref.norm()))
+    assert cos > 0.98, cos
+    for (k, p), (_, q) in zip(m16.named_parameters(), ref.named_parameters()):
+        c = float((p.grad.double().cpu().flatten() @ q.grad.double().flatten()) / (p.grad.double().norm().cpu() * q.grad.double().norm() + 1e-30))
+        assert c > 0.95, (k, c)
+
+
+@pytest.mark.parametrize('name,batch', [('base', 512), ('small', 256)])
+def test_full_configuration_properties(name, batch):
+    """BASELINE.json configs[1] / configs[2] as benchmarked: from_defined sizes, bf16, dropout 0.1, full depth and batch"""
+    conf = E.EcgVitConfig.from_defined(f'ecg-vit-{name}')
+    conf.max_signal_length, conf.patch_size = 5000, 20
+    assert conf.hidden_dropout_prob == 0.1 and conf.attention_probs_dropout_prob == 0.1
+    torch.manual_seed(77)
+    m = E.EcgVit(config=conf, compute_dtype=BF16).cuda().train()
+    x, y = E.workload.synthetic_batch(batch, length=5000, seed=77)
+    x, y = x.cuda(), y.cuda()
+    eng = m._engine()
+    # bit-identical rerun under a pinned dropout seed; another seed draws other masks
+    la, _, ma = (t.clone() for t in eng.forward(x, y, None, training=True, seed=4711, want_mean=True))
+    lb, _, mb = (t.clone() for t in eng.forward(x, y, None, training=True, seed=4711, want_mean=True))
+    lc, _, mc = (t.clone() for t in eng.forward(x, y, None, training=True, seed=4712, want_mean=True))
+    assert torch.isfinite(la).all() and torch.isfinite(ma).all()
+    assert torch.equal(la, lb) and torch.equal(ma, mb) and not torch.equal(la, lc)
+    # batch-slice invariance in eval: a record's logits do not depend on the batch it sits in
+    m.eval()
+    with torch.no_grad():
+        full = m(sample_values=x).logits.clone()
+        part = m(sample_values=x[37:101].contiguous()).logits.clone()
+    assert torch.isfinite(full).all() and torch.equal(full[37:101], part)
+    m.train()
+    # three fused steps (fwd + BCE + bwd + clip + AdamW): finite, and the loss on the same batch falls
+    step = E.HipTrainStep(m, E.get_train_args(dict(train_batch_size=batch, num_train_epoch=1, warmup_ratio=0.0), n_train=batch * 20))
+    losses = [float(step.step(x, y)[0]) for _ in range(3)]
+    step.finish()
+    assert all(l == l and abs(l) < 1e4 for l in losses), losses
+    assert losses[2] < losses[0], losses
+    assert 0.0 < step.grad_norm() < float('inf')
+
+
+def test_autograd_surface_accumulates_gradients():
+    """`zero_grad(set_to_none=False)` and two-micro-batch accumulation through loss.backward(): `.grad` aliases the engine's flat buffer
+    after the first backward, the second must ADD to it (not double the new gradient)"""
+    ref, m, x, y = _pair('small', 1, 8, F32)
+    xc, yc = x.cuda(), y.cuda()
+    # oracle: accumulate two micro-batches
+    for sl in (slice(0, 4), slice(4, 8)):
+        ref(sample_values=x[sl], labels=y[sl]).loss.backward()
+    for sl in (slice(0, 4), slice(4, 8)):
+        m(sample_values=xc[sl].contiguous(), labels=yc[sl].contiguous()).loss.backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 1e-4, (k, rel_err(p.grad, q.grad))
+    # zero in place, then one backward: g, not 2 g
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    opt.zero_grad(set_to_none=False)
+    ref.zero_grad(set_to_none=False)
+    ref(sample_values=x, labels=y).loss.backward()
+    m(sample_values=xc, labels=yc).loss.backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad, q.grad) < 1e-4, (k, rel_err(p.grad, q.grad))
+
+
+def test_fused_step_hands_out_copies():
+    ref, m, x, y = _pair('small', 1, 4, BF16)
+    step = E.HipTrainStep(m, dict(n_step=10))
+    l0, g0 = step.step(x.cuda(), y.cuda())
+    keep_l, keep_g = float(l0), g0.clone()
+    l1, _ = step.step(x.cuda(), y.cuda())
+    assert float(l0) == keep_l and torch.equal(g0, keep_g) and float(l1) != keep_l   # the first step's results were not overwritten
+
+
+def test_masked_objective_rejects_bad_indices():
+    conf = E.EcgVitConfig(max_signal_length=1000, patch_size=20, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256)
+    mm = E.MaskedEcgVit(E.EcgVit(config=conf, compute_dtype=BF16), mask_ratio=0.5).cuda().train()
+    x, _ = E.workload.synthetic_batch(3, length=1000, seed=1)
+    x = x.cuda()
+    good = mm.random_mask_indices(3, generator=torch.Generator().manual_seed(0))
+    assert torch.isfinite(mm(x, good).loss)
+    for bad in (good.clone().fill_(3),                       # duplicates inside a record
+                torch.cat([good[:, :-1], torch.full((3, 1), 50)], 1),   # 50 == n_patch: out of range
+                good[:2],                                    # wrong batch
+                good.float()):                               # not an integer tensor
+        with pytest.raises(ValueError):
+            mm(x, bad)
+        with pytest.raises(ValueError):
+            E.HipTrainStep(mm, dict(n_step=5)).step_masked(x, bad)

@@ -704,7 +704,6 @@ def test_attention_bwd_persistent_stream(B, h, N, p):
     """the persistent backward (slab stream continuous across (record, head) items, counted waits, 1-3 items per workgroup) against
     the double-precision reference (p = 0) and against the one-item-per-workgroup kernel on the same dropout mask (p > 0);
     ragged N (a whole wave of keys out of range at N = 200 / 130), repeated launches bit-identical (a stream race would show)"""
-    import os
     g = torch.Generator().manual_seed(B * 1000 + N)
     dh = 64
     d = h * dh
@@ -717,21 +716,18 @@ def test_attention_bwd_persistent_stream(B, h, N, p):
     check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_fwd')
 
     def bwd(persist):
-        os.environ['ECGVIT_ATTN_PERSIST'] = '1' if persist else '0'
+        fn = lib().ecgvit_attention_bwd if persist else lib().ecgvit_attention_bwd_oneitem
         r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=BF16)
-        check(lib().ecgvit_attention_bwd(ptr(qd), ptr(out), ptr(dod), ptr(lse), ptr(r), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_bwd')
+        check(fn(ptr(qd), ptr(out), ptr(dod), ptr(lse), ptr(r), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_bwd')
         torch.cuda.synchronize()
         return r
-    try:
-        new = bwd(True)
-        assert torch.isfinite(new.float()).all()
-        for _ in range(5):
-            assert torch.equal(bwd(True), new)
-        if N <= 256:                                             # the one-item kernel holds at most 256 keys
-            old = bwd(False)
-            assert rel_err(new, old.float().double().cpu()) < 2e-3
-    finally:
-        os.environ.pop('ECGVIT_ATTN_PERSIST', None)
+    new = bwd(True)
+    assert torch.isfinite(new.float()).all()
+    for _ in range(5):
+        assert torch.equal(bwd(True), new)
+    if N <= 256:                                             # the one-item kernel holds at most 256 keys
+        old = bwd(False)
+        assert rel_err(new, old.float().double().cpu()) < 2e-3
     if p == 0.0:
         qr = qkv.double().requires_grad_(True)
         o_ref, _, _ = _attn_ref(qr, B, N, h, dh, scale)

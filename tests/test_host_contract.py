@@ -154,9 +154,18 @@ def test_ptbxl_splits_multi_hot_and_feeder_order(tmp_path):
     e0 = torch.cat([b['sample_values'] for b in fs]); e1 = torch.cat([b['sample_values'] for b in fs])
     key = lambda t: sorted(t[:, 0, 0].tolist())
     assert key(e0) == key(x) == key(e1) and not torch.equal(e0, e1)
-    parts = [torch.cat([b['sample_values'] for b in E.DeviceFeeder(rec, idx, mh[idx], 8, shuffle=True, seed=5, device='cpu', rank=r, world=2)])
-             for r in range(2)]
-    assert torch.equal(torch.cat(parts), e0)
+    feeders = [E.DeviceFeeder(rec, idx, mh[idx], 8, shuffle=True, seed=5, device='cpu', rank=r, world=2) for r in range(2)]
+    batches = [list(f) for f in feeders]
+    # every rank yields the SAME number of batches of the SAME sizes (a collective train step would hang otherwise), also for odd n:
+    # the epoch's order wraps around to fill the last shard
+    assert len(batches[0]) == len(batches[1]) == len(feeders[0]) == len(feeders[1])
+    assert [b['sample_values'].shape[0] for b in batches[0]] == [b['sample_values'].shape[0] for b in batches[1]]
+    parts = torch.cat([torch.cat([b['sample_values'] for b in bs]) for bs in batches])
+    n_tr = len(idx)
+    assert torch.equal(parts[:n_tr], e0) and torch.equal(parts[n_tr:], e0[:len(parts) - n_tr]) and len(parts) - n_tr == (n_tr % 2)
+    odd = idx[:len(idx) - 1 + (len(idx) % 2)]           # force an odd record count: n = 2k + 1 -> k + 1 records on both ranks
+    fo = [E.DeviceFeeder(rec, odd, mh[odd], 4, shuffle=False, device='cpu', rank=r, world=2) for r in range(2)]
+    assert len(odd) % 2 == 1 and len(fo[0]) == len(fo[1]) == ((len(odd) + 1) // 2 + 3) // 4
     try:
         import h5py  # noqa: F401
     except ImportError:

@@ -35,6 +35,46 @@ def test_patch_gather_bit_exact():
         assert z[key][b, p, j * 12 + c] == int(x[b, c, p * P + j])
 
 
+def test_patch_gather_pinned_to_einops():
+    """the index map of the patch gather is pinned to a REAL dependency of the reference: the fixture holds what
+    `einops.rearrange(x.unsqueeze(-2), 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)', p1=1, p2=P)` itself returns
+    (oracle/make_golden_einops.py); the oracle's gather and the stand-in-generated fixture must both equal it"""
+    z = np.load(os.path.join(GOLDEN, 'patch_gather_einops.npz'))
+    zo = np.load(os.path.join(GOLDEN, 'patch_gather.npz'))
+    keys = [k for k in z.files if k != 'einops_version']
+    assert len(keys) == 4
+    for key in keys:
+        L, P = (int(s[1:]) for s in key.split('_'))
+        x = np.arange(2 * 12 * L, dtype=np.int32).reshape(2, 12, L)
+        assert np.array_equal(O.patch_gather_np(x, P), z[key]), key
+        assert np.array_equal(O.patch_gather(torch.from_numpy(x), P).numpy(), z[key]), key
+        if key in zo.files:
+            assert np.array_equal(zo[key], z[key]), key
+    try:
+        import einops
+    except ImportError:
+        return
+    x = np.random.default_rng(0).integers(-9, 9, size=(3, 12, 120)).astype(np.int32)   # live einops, where it is installed
+    assert np.array_equal(O.patch_gather_np(x, 20), einops.rearrange(x[:, :, None, :], 'b c (h p1) (w p2) -> b (h w) (p1 p2 c)', p1=1, p2=20))
+
+
+def test_workload_helpers_match_the_oracle_copies():
+    """bench.py takes its synthetic inputs and its FLOP formula from the PACKAGE (no oracle import outside the cpu_baseline leg);
+    the oracle keeps copies for the tests: they must stay identical"""
+    import ecg_representation_learning_amd as E
+    for seed, b, L in ((77, 3, 400), (5, 2, 5000)):
+        xa, ya = E.workload.synthetic_batch(b, length=L, seed=seed)
+        xb, yb = O.synthetic_batch(b, length=L, seed=seed)
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
+    for name in ('ecg-vit-base', 'ecg-vit-small', 'ecg-vit-large'):
+        conf = E.EcgVitConfig.from_defined(name)
+        conf.max_signal_length, conf.patch_size = 5000, 20
+        assert E.workload.train_flops_per_record(conf) == O.train_flops_per_record(conf)
+    conf = E.EcgVitConfig.from_defined('ecg-vit-base')
+    conf.max_signal_length, conf.patch_size = 5000, 20
+    assert abs(E.workload.train_flops_per_record(conf) / 1e9 - 135.16) < 0.01      # SURVEY 8d: 135.16 GFLOP per record
+
+
 @pytest.mark.parametrize('tag', TAGS)
 def test_forward_loss_and_intermediates(tag):
     z, spec, model = build(tag)

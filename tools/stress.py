@@ -48,12 +48,11 @@ while time.time() < t_end:
         out = torch.empty(B * N, d, device='cuda', dtype=bf); lse = torch.zeros(B * h * N, device='cuda')
         check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'f')
         res = []
-        for pers in ('1', '1', '1', '0' if N <= 256 else '1'):   # the one-item kernel covers N <= 256 only
-            os.environ['ECGVIT_ATTN_PERSIST'] = pers
+        for pers in (True, True, True, N > 256):   # the one-item kernel covers N <= 256 only
+            fn = lib().ecgvit_attention_bwd if pers else lib().ecgvit_attention_bwd_oneitem
             r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=bf)
-            check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
+            check(fn(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
             torch.cuda.synchronize(); res.append(r)
-        os.environ.pop('ECGVIT_ATTN_PERSIST', None)
         if not (torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])):
             bad += 1; print('ATTN NONDETERMINISTIC', B, h, N, p, flush=True)
         err = float((res[0].float() - res[3].float()).norm() / res[3].float().norm())
