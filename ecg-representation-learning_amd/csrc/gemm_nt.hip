@@ -518,13 +518,17 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #ifdef ECGVIT_TOOLS
     {   // tools build only: whole-step A/B of the diag bits (bench.py under ECGVIT_HIP_LIB=libecgvit_hip_tools.so)
         static const int env_diag = [] { const char *e = getenv("ECGVIT_NT_DIAG"); return e ? atoi(e) : 0; }();
+        static const int env_g = [] { const char *e = getenv("ECGVIT_NT_G"); return e ? atoi(e) : 0; }();
         diag |= env_diag;
+        if (raster_g == 0) raster_g = env_g;
     }
 #endif
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : tiles_n;
     const EpiParams e = make_epi(d);
-    const dim3 grid((unsigned)std::min(ntile, 256)), block(512);
+    // persistent (one workgroup per CU, static shares) unless the caller asks for dispatcher-balanced chunks of ~k tiles
+    const int tpw = d->tiles_per_workgroup;
+    const dim3 grid((unsigned)(tpw > 0 ? std::max(std::min(ntile, 256), (ntile + tpw - 1) / tpw) : std::min(ntile, 256))), block(512);
     const int fl = d->epilogue;
     constexpr int F_LIN = ECGVIT_EPI_BIAS | ECGVIT_EPI_RESIDUAL;
     constexpr int F_UP = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX;
@@ -565,6 +569,20 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 }
 
 #ifdef ECGVIT_TOOLS
+// stand-in for a collective's kernel: n workgroups that each hold a whole CU (all of its LDS) for `cycles` shader cycles
+__global__ __launch_bounds__(64) void tools_occupy_kernel(unsigned long long cycles, unsigned int *done) {
+    __shared__ char hold[LDS_BYTES];
+    hold[threadIdx.x] = 1;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+    if (threadIdx.x == 0 && hold[0]) atomicAdd(done, 1u);
+}
+extern "C" int ecgvit_tools_occupy(int n_cus, unsigned long long cycles, unsigned int *done, void *stream) {
+    hipLaunchKernelGGL(tools_occupy_kernel, dim3(n_cus), dim3(64), 0, as_stream(stream), cycles, done);
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
 extern "C" int ecgvit_tools_nt_stamps(unsigned long long *h_out) {   // host buffer of 256*8 words
     return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_nt_stamps), sizeof(unsigned long long) * 256 * 8) == hipSuccess ? ECGVIT_OK : ECGVIT_ELAUNCH;
 }

@@ -19,6 +19,10 @@ GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD_AUX, EPI_MUL_AUX = 128, 256
 
+# default of `ecgvit_gemm_desc.tiles_per_workgroup` for every GEMM issued through `gemm()`: 0 = persistent static shares (the launch
+# owns the GPU); HipTrainStep sets it to 2 while gradient all-reduce buckets overlap the backward pass (RCCL kernels hold CUs)
+GEMM_TILES_PER_WORKGROUP = 0
+
 _ERR = {1: 'ECGVIT_EINVAL (unsupported shape / argument)', 2: 'ECGVIT_ELAUNCH (HIP launch failure)'}
 
 
@@ -35,7 +39,7 @@ class GemmDesc(Structure):
         ('C', c_void_p), ('ldc', c_int64), ('strideC1', c_int64), ('strideC2', c_int64),
         ('bias', c_void_p), ('residual', c_void_p), ('ldr', c_int64), ('aux', c_void_p), ('ldaux', c_int64),
         ('alpha', c_float), ('dropout_p', c_float), ('dropout_seed', c_uint64),
-        ('workspace', c_void_p), ('workspace_bytes', c_int64), ('colsum_out', c_void_p),
+        ('workspace', c_void_p), ('workspace_bytes', c_int64), ('colsum_out', c_void_p), ('tiles_per_workgroup', c_int32),
     ]
 
 
@@ -135,7 +139,7 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
               alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-              a_off=0, b_off=0, c_off=0, colsum_out=None):
+              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None):
     """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
     d = GemmDesc()
@@ -147,6 +151,7 @@ def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None,
     d.bias, d.residual, d.ldr, d.aux, d.ldaux = ptr(bias), ptr(residual), ldr, ptr(aux), ldaux
     d.alpha, d.dropout_p, d.dropout_seed = alpha, dropout_p, seed
     d.colsum_out = ptr(colsum_out)
+    d.tiles_per_workgroup = GEMM_TILES_PER_WORKGROUP if tiles_per_workgroup is None else tiles_per_workgroup
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     return d
