@@ -538,6 +538,30 @@ def test_gemm_bf16_large_shapes(layout, shape):
         assert rel_err(C, ref + bias.double() + res.double()) < 4e-3
 
 
+def test_gemm_bf16_chunked_dispatch_equals_persistent():
+    """`tiles_per_workgroup` (dispatcher-balanced chunks for launches that share the GPU with collectives) changes only which workgroup
+    computes a tile: outputs, saved aux and fused column sums are bit-identical to the persistent launch, ragged M / N included"""
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 70011, 776, 256
+    A = torch.randn(M, K, generator=g).to(BF16).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.1).to(BF16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    aux = torch.rand(M, N, generator=g).to(BF16).cuda()
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device='cuda')
+    outs = []
+    for tpw in (0, 1, 2, 5):
+        C = torch.full((M, N), float('nan'), device='cuda', dtype=BF16)
+        C2 = torch.full((M, N), float('nan'), device='cuda', dtype=BF16)
+        cs = torch.zeros(N, device='cuda')
+        hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_DROPOUT, bias=bias, dropout_p=0.1, seed=5, tiles_per_workgroup=tpw)
+        hip.gemm(hip.GEMM_NT, A, B, C2, M, N, K, K, K, N, epilogue=hip.EPI_MUL_AUX | hip.EPI_COLSUM, aux=aux, ldaux=N, workspace=ws, colsum_out=cs,
+                 tiles_per_workgroup=tpw)
+        outs.append((C, C2, cs))
+    for C, C2, cs in outs[1:]:
+        assert torch.equal(C, outs[0][0]) and torch.equal(C2, outs[0][1]) and torch.equal(cs, outs[0][2])
+    assert torch.isfinite(outs[0][0].float()).all() and rel_err(outs[0][2], outs[0][1].float().sum(0)) < 1e-5
+
+
 def test_gemm_bf16_persistent_forward_is_race_free_and_exact():
     """the quadrant-phased persistent forward kernel (continuous operand stream across output tiles, counted waits): small-integer
     operands make every product and sum exact in f32, so the result must EQUAL the integer reference bit for bit, on every one of
