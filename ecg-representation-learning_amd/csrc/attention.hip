@@ -934,7 +934,9 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     const uint32_t th = dropout_threshold(dropout_p);
     const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
     const int nitems = B * h;
-    const dim3 pg((unsigned)(nitems < 256 ? nitems : 256));
+    // three workgroups' worth of items per CU slot: the hardware dispatcher hands them out as CUs free up, so a launch that shares the
+    // GPU with a collective's kernels is not left with late workgroups a full static share behind (one per CU measured the same alone)
+    const dim3 pg((unsigned)(nitems < 768 ? nitems : 768));
 #define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0)
     if (th) PERS(true, false, 0); else PERS(false, false, 0);
     ECGVIT_CHECK_LAUNCH();

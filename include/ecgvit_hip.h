@@ -84,11 +84,12 @@ typedef struct ecgvit_gemm_desc {
     void *workspace;      /* optional split-K slabs (bf16 TN); see ecgvit_gemm_workspace */
     int64_t workspace_bytes;
     float *colsum_out;    /* [N] f32, with ECGVIT_EPI_COLSUM */
-    int32_t tiles_per_workgroup; /* large A.B^T products only. 0: persistent launch, one workgroup per CU walks a static share of the
+    int32_t tiles_per_workgroup; /* large products only. 0: persistent launch, one workgroup per CU walks a static share of the
                              output tiles (fastest when the launch owns the GPU). k > 0: ceil(tiles / k) workgroups of about k tiles
                              each, handed out by the hardware dispatcher as CUs free up -- use it when other kernels (RCCL
                              collectives overlapped with the backward pass) hold CUs, where a static share would leave the
-                             workgroups that start late a full share behind.  Results are identical either way. */
+                             workgroups that start late a full share behind (large weight-gradient products then cut three times as many K-slices).
+                             A.B^T results are identical either way; the weight-gradient sum order follows the slice count. */
 } ecgvit_gemm_desc;
 
 int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
