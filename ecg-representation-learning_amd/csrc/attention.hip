@@ -153,7 +153,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
         bf16x8 qf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
-        const uint32_t rowidx = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 1) & ~1);   // row pitch rounded to even: keys (2j, 2j+1) share one hash
+        const uint32_t rowquad = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 3) >> 2);   // first key quad of this query's row (4 keys share one hash)
+        const uint32_t smix = seed_mix(seed);
 
         f32x16 o[2];
 #pragma unroll
@@ -196,14 +197,14 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
-            if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout)
-                const uint32_t hb = pair_base(seed, rowidx + (uint32_t)(kt * 32 + 4 * lh));   // one Weyl multiply per 32-key tile
+            if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout); the
+                // 1/(1-p) rescale is folded into the final normalisation.  My 16 keys are 4 quads: kt*32 + 8g + 4*lh + {0..3}
+                const uint32_t hb = (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix;
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    // keys (r&3) + 8*(r>>2) + 4*lh, pairs (r, r+1): pair offset ((r&3)>>1) + 4*(r>>2) from the tile's first pair
-                    const uint32_t hh = pair_finish(hb + (uint32_t)(((r & 3) >> 1) + 4 * (r >> 2)) * ECGVIT_WEYL);
-                    s[r] *= (hh & 0xFFFFu) >= thresh ? inv_keep : 0.f;
-                    s[r + 1] *= (hh >> 16) >= thresh ? inv_keep : 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t hh = pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[4 * g + k] = ((hh >> (8 * k)) & 0xFFu) >= thresh ? s[4 * g + k] : 0.f;
                 }
             }
 #pragma unroll
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
         }
         l += __shfl_xor(l, 32, 64);
         if (q < N) {
-            const float inv = 1.0f / l;
+            const float inv = inv_keep / l;   // inv_keep = 1 without dropout
             bf16_t *orow = out + ((int64_t)b * N + q) * d + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -322,12 +323,12 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 
     for (int qb = (ablate & 4) ? nqb : 0; qb < nqb; ++qb) {
         const char *Qrow = Qimg + qb * 4096, *dOrow = dOimg + qb * 4096;
-        // dropout: element index = ((bh*N + q) * NP + key), NP = N rounded up to even (the forward kernel's function); keys (2j, 2j+1)
-        // of one query share a hash and sit on adjacent lanes, so each lane finishes the hashes of TWO of its four queries per group
-        // and takes the other two from its neighbour (DPP quad_perm swap): 2 hashes per 4 elements instead of 4
-        const uint32_t hstep = (uint32_t)((N + 1) >> 1) * ECGVIT_WEYL;   // one query down = NP/2 pairs
-        const uint32_t hq0 = seed_mix(seed) + (((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)(mykey >> 1)) * ECGVIT_WEYL;
-        const uint32_t podd = (uint32_t)(lane & 1);
+        // dropout: the forward kernel's function -- quad = (bh*N + q) * ceil(N/4) + key/4, byte = key & 3.  The 4 keys of a quad sit on 4
+        // adjacent lanes: lane j of the quad hashes query j of each group of four and the others take it by a quad_perm broadcast
+        const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
+        const uint32_t hstep = qpitch * ECGVIT_WEYL;   // one query down
+        const uint32_t hq0 = seed_mix(seed) + (((uint32_t)bh * (uint32_t)N + (uint32_t)(qb * 32)) * qpitch + (uint32_t)(mykey >> 2)) * ECGVIT_WEYL;
+        const uint32_t bsh = (uint32_t)(mykey & 3) * 8u, lq = (uint32_t)(lane & 3);
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -343,12 +344,11 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
             const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_s[qb * 32 + 8 * g4 + 4 * lh]);
             uint32_t hk[4];
             if constexpr (DROP) {
-                const uint32_t hg = hq0 + (uint32_t)(8 * g4 + 4 * lh) * hstep + (podd * 2u) * hstep;   // my two queries: k = 2*podd, 2*podd + 1
-                const uint32_t mine0 = pair_finish(hg), mine1 = pair_finish(hg + hstep);
-                const uint32_t oth0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xB1, 0xF, 0xF, true);   // lane ^ 1
-                const uint32_t oth1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xB1, 0xF, 0xF, true);
-                hk[0] = podd ? oth0 : mine0; hk[1] = podd ? oth1 : mine1;
-                hk[2] = podd ? mine0 : oth0; hk[3] = podd ? mine1 : oth1;
+                const uint32_t mine = pair_finish(hq0 + ((uint32_t)(8 * g4 + 4 * lh) + lq) * hstep);   // query k = lane & 3 of this group
+                hk[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, true);   // quad_perm:[0,0,0,0]
+                hk[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, true);   // [1,1,1,1]
+                hk[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, true);   // [2,2,2,2]
+                hk[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, true);   // [3,3,3,3]
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
                 float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
                 float g = dp[r];
                 if constexpr (DROP) {
-                    const float mlt = ((hk[k] >> (podd * 16u)) & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+                    const float mlt = ((hk[k] >> bsh) & 0xFFu) >= thresh ? inv_keep : 0.f;
                     g *= mlt;
                     s[r] = p * mlt;  // dropped probabilities feed dV
                 } else {
@@ -624,9 +624,10 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 
             const char *Qrow = slab0 + slot * SLAB, *dOrow = Qrow + 4096;
             const float *delta_c = delta_s + (jj & 1) * 32;
-            const uint32_t hstep = (uint32_t)((N + 1) >> 1) * ECGVIT_WEYL;
-            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * (uint32_t)((N + 1) >> 1) + (uint32_t)((mykey + k0) >> 1)) * ECGVIT_WEYL;
-            const uint32_t podd = (uint32_t)(lane & 1);
+            const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
+            const uint32_t hstep = qpitch * ECGVIT_WEYL;
+            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * qpitch + (uint32_t)((mykey + k0) >> 2)) * ECGVIT_WEYL;
+            const uint32_t bsh = (uint32_t)((mykey + k0) & 3) * 8u, lq = (uint32_t)(lane & 3);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -641,13 +642,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_c[8 * g4 + 4 * lh]);
                 uint32_t hk[4];
                 if constexpr (DROP) {
-                    const uint32_t hg = hq0 + (uint32_t)(8 * g4 + 4 * lh) * hstep + (podd * 2u) * hstep;
-                    const uint32_t mine0 = pair_finish(hg), mine1 = pair_finish(hg + hstep);
-                    // queries k = 0, 1 were hashed by the even lane of each key pair, k = 2, 3 by the odd lane: quad_perm broadcasts
-                    hk[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xA0, 0xF, 0xF, true);   // quad_perm:[0,0,2,2]
-                    hk[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xA0, 0xF, 0xF, true);
-                    hk[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine0, 0xF5, 0xF, 0xF, true);   // quad_perm:[1,1,3,3]
-                    hk[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine1, 0xF5, 0xF, 0xF, true);
+                    const uint32_t mine = pair_finish(hq0 + ((uint32_t)(8 * g4 + 4 * lh) + lq) * hstep);   // query k = lane & 3 of this group
+                    hk[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, true);   // quad_perm:[0,0,0,0]
+                    hk[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, true);
+                    hk[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, true);
+                    hk[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, true);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -655,7 +654,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                     float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
                     float g = dp[r];
                     if constexpr (DROP) {
-                        const float mlt = ((hk[k] >> (podd * 16u)) & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+                        const float mlt = ((hk[k] >> bsh) & 0xFFu) >= thresh ? inv_keep : 0.f;
                         g *= mlt;
                         s[r] = p * mlt;
                     } else {
@@ -889,8 +888,8 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
                          uint64_t seed, int dtype, void *stream) {
     if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) % 16) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const uint32_t th = dropout_threshold8(dropout_p);
+    const float ik = dropout_inv_keep8(dropout_p);
     dim3 grid((unsigned)(B * h));
     const size_t lds = (size_t)((N + 31) / 32) * 32 * 128 * 2;
     static bool attr_set = false;
@@ -915,8 +914,8 @@ static int attention_bwd_args_ok(const void *qkv, const void *out, const void *d
 int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
                                  int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype) || N > 256) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const uint32_t th = dropout_threshold8(dropout_p);
+    const float ik = dropout_inv_keep8(dropout_p);
     dim3 grid((unsigned)(B * h));
 #define BWD(NKT, DR) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, DR>), grid, dim3(NKT * 64), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, 0)
     if (N <= 128) { if (th) BWD(4, true); else BWD(4, false); }
@@ -931,8 +930,8 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype)) return ECGVIT_EINVAL;
     if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31))   // short sequences / 32-bit buffer offsets exhausted
         return ecgvit_attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    const uint32_t th = dropout_threshold8(dropout_p);
+    const float ik = dropout_inv_keep8(dropout_p);
     const int nitems = B * h;
     // three workgroups' worth of items per CU slot: the hardware dispatcher hands them out as CUs free up, so a launch that shares the
     // GPU with a collective's kernels is not left with late workgroups a full static share behind (one per CU measured the same alone)

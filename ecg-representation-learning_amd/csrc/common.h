@@ -134,6 +134,20 @@ __device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] *= m[k];
 }
+// ---- attention-probability dropout: one hash per FOUR consecutive keys of a query, 8 random bits each (threshold = round(p * 256),
+// as FlashAttention's kernels quantise p; the kept values are rescaled by the exact 256 / (256 - threshold), so the estimator stays
+// unbiased for the probability actually applied).  The score tensor holds 4e8 elements per layer at the benchmark shape and its
+// kernels are VALU-bound: the 16-bit pair form above costs 8.5 instruction slots per element there, this one 4.5-5.
+//   element (bh, q, key): quad = ((bh * N + q) * ceil(N / 4) + key / 4), byte = key & 3, keep iff byte >= threshold.
+__device__ __forceinline__ uint32_t quad_hash(uint32_t seedmix, uint32_t quad) { return pair_finish(quad * ECGVIT_WEYL + seedmix); }
+static inline uint32_t dropout_threshold8(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 256.0 + 0.5;
+    if (t > 255.0) t = 255.0;
+    return (uint32_t)t;
+}
+static inline float dropout_inv_keep8(float p) { return 256.0f / (256.0f - (float)dropout_threshold8(p)); }
+
 static inline uint32_t dropout_threshold(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 65536.0 + 0.5;

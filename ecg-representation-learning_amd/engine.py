@@ -25,12 +25,6 @@ def _align(n, a=8):
     return (n + a - 1) // a * a
 
 
-# 256 < N <= 512 tokens: the fused persistent attention backward runs as two key windows.  True = recompute the probabilities with the
-# exact-f32 batched kernels of the parity path instead (a slower, independent route kept for cross-checks: set it on the module
-# before the engine allocates).
-_LONG_FALLBACK = False
-
-
 class ParamLayout:
     """name -> (offset, shape) inside one flat f32 buffer; every tensor starts on a 32-B boundary so the same
     offsets address the bf16 shadow on 16-B boundaries (vector loads everywhere)."""
@@ -188,13 +182,6 @@ class VitEngine:
                  dxm=e(M, d))
         if T == torch.float32:
             a.update(pd=e(B * h * N * N), dp=e(B * h * N * N))
-        elif N > 256 and _LONG_FALLBACK:
-            # long records (seq = 500 patches), fallback only: the backward recomputes the probabilities with the exact-f32 batched
-            # kernels of the parity path on f32 copies (the shipped path runs the fused persistent backward as two 256-key windows)
-            NP = (N + 1) & ~1   # row pitch of the fused kernel's dropout index
-            f32 = torch.float32
-            a.update(lq=e(M, 3 * d, dt=f32), ldo=e(M, d, dt=f32), ldq=e(M, 3 * d, dt=f32), lp=e(B * h * N * NP, dt=f32),
-                     ldp=e(B * h * N * NP, dt=f32), lpd=e(B * h * N * NP, dt=f32))
         l = lib()
         ws = max(l.ecgvit_layernorm_bwd_workspace(M, d), l.ecgvit_colsum_workspace(M, max(f, 3 * d)), 8 * ((M + 255) // 256) * f, 4096)
         if T == torch.bfloat16:
@@ -492,9 +479,7 @@ class VitEngine:
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
             self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d)
-            if self.dtype == torch.bfloat16 and N > 256 and _LONG_FALLBACK:
-                self._attn_bwd_long(L, B, ph, s0 + 1)
-            elif self.dtype == torch.bfloat16:
+            if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
                                              dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
             else:
@@ -537,32 +522,6 @@ class VitEngine:
         # dQ = dS K ; dK = dS^T Q
         hip.gemm(GEMM_NN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, b_off=d)
         hip.gemm(GEMM_TN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, c_off=d)
-
-    def _attn_bwd_long(self, L, B, ph, seed):
-        """bf16 engine, 256 < N <= 512: probabilities recomputed from f32 copies of qkv (same arithmetic as the parity path), the fused
-        forward's dropout mask reproduced through its own element index (row pitch N rounded up to even), result cast back to bf16"""
-        d, h, dh, N = self.d, self.h, self.dh, self.T
-        a, l, st = self.act, lib(), stream()
-        NP = (N + 1) & ~1
-        M = B * N
-        q32, do32, dq32, P, dP, Pd = a['lq'], a['ldo'], a['ldq'], a['lp'], a['ldp'], a['lpd']
-        check(l.ecgvit_cast_bf16_to_f32(ptr(L['qkv']), ptr(q32), M * 3 * d, st), 'cast')
-        check(l.ecgvit_cast_bf16_to_f32(ptr(a['dattn']), ptr(do32), M * d, st), 'cast')
-        sq, so, sp = (N * 3 * d, dh), (N * d, dh), (h * N * NP, N * NP)
-        hip.gemm(GEMM_NT, q32, q32, P, N, N, dh, 3 * d, 3 * d, NP, alpha=self.scale, batch=(B, h), strideA=sq, strideB=sq, strideC=sp, b_off=d)
-        check(l.ecgvit_softmax_rows(ptr(P), B * h * N, N, NP, st), 'softmax_rows')
-        src = P
-        if ph > 0:
-            check(l.ecgvit_dropout_apply(ptr(P), ptr(Pd), B * h * N * NP, ph, seed, hip.F32, st), 'dropout_apply')
-            src = Pd
-        hip.gemm(GEMM_TN, src, do32, dq32, N, dh, N, NP, d, 3 * d, batch=(B, h), strideA=sp, strideB=so, strideC=sq, c_off=2 * d)       # dV
-        hip.gemm(GEMM_NT, do32, q32, dP, N, N, dh, d, 3 * d, NP, batch=(B, h), strideA=so, strideB=sq, strideC=sp, b_off=2 * d)         # dPd
-        if ph > 0:
-            check(l.ecgvit_dropout_apply(ptr(dP), ptr(dP), B * h * N * NP, ph, seed, hip.F32, st), 'dropout_apply')
-        check(l.ecgvit_softmax_bwd_rows(ptr(P), ptr(dP), B * h * N, N, NP, self.scale, st), 'softmax_bwd_rows')                            # dS
-        hip.gemm(GEMM_NN, dP, q32, dq32, N, dh, N, NP, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, b_off=d)          # dQ
-        hip.gemm(GEMM_TN, dP, q32, dq32, N, dh, N, NP, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, c_off=d)          # dK
-        check(l.ecgvit_cast_f32_to_bf16(ptr(dq32), ptr(a['dqkv']), M * 3 * d, st), 'cast')
 
     # ---------------------------------------------------------------- per-layer attention probabilities (f3)
     def attention_probs(self, layer):

@@ -413,6 +413,45 @@ def test_attention_bf16_dropout_mask_consistent_fwd_bwd():
     assert rel_err(dqkv, qr.grad) < 3e-2
 
 
+def test_attention_dropout_mask_statistics():
+    """the attention-probability mask (one hash per 4 consecutive keys, 8 bits each): V = identity exposes it.  Keep rate = the
+    quantised probability 1 - round(256 p)/256 to sampling error; keys inside one hash word, neighbouring words, neighbouring queries
+    and different seeds are uncorrelated (< 5e-3 on 1 M elements); a rerun reproduces it bit for bit"""
+    B, h, dh, N = 64, 4, 64, 64
+    g = torch.Generator().manual_seed(2)
+    qkv = torch.zeros(B * N, 3 * h * dh)
+    for hd in range(h):
+        qkv[:, 2 * h * dh + hd * dh:2 * h * dh + (hd + 1) * dh] = torch.eye(N).repeat(B, 1)      # V = I per head; Q = K = 0: uniform P
+    qd = dev(qkv.to(BF16))
+    masks = {}
+    for p, seed in ((0.1, 7), (0.1, 8), (0.3, 7)):
+        out = torch.zeros(B * N, h * dh, device='cuda', dtype=BF16)
+        lse = torch.zeros(B * h * N, device='cuda')
+        for rep in range(2):
+            check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, 0.125, p, seed, hip.BF16, stream()), 'attn_fwd')
+            m = (out.float() != 0).view(B, N, h, N).permute(0, 2, 1, 3).contiguous()              # [b, head, query, key]
+            if rep == 0:
+                masks[(p, seed)] = m
+            else:
+                assert torch.equal(m, masks[(p, seed)])
+        keep = m.double().mean().item()
+        want = 1.0 - round(256 * p) / 256.0
+        assert abs(keep - want) < 2e-3, (p, keep, want)
+        kept = out.float()[out.float() != 0]
+        assert abs(kept.mean().item() * N - 1.0 / want) < 2e-2 / want          # kept probabilities are scaled by exactly 1 / keep-rate
+    m = masks[(0.1, 7)].double()
+
+    def corr(a, b):
+        a, b = a.flatten() - a.mean(), b.flatten() - b.mean()
+        return abs(float((a * b).mean() / (a.std() * b.std())))
+    assert corr(m[..., 0::2], m[..., 1::2]) < 5e-3            # keys 2j, 2j+1: same hash word
+    assert corr(m[..., 0::4], m[..., 3::4]) < 5e-3            # first / last byte of a word
+    assert corr(m[..., 3:-4:4], m[..., 4::4][..., :m[..., 3:-4:4].shape[-1]]) < 5e-3   # neighbouring words
+    assert corr(m[:, :, :-1], m[:, :, 1:]) < 5e-3             # neighbouring queries
+    assert corr(m[:, :-1], m[:, 1:]) < 5e-3                   # neighbouring heads
+    assert corr(m, masks[(0.1, 8)].double()) < 5e-3           # another seed
+
+
 # ------------------------------------------------------------------------------------------------------ optimiser
 def test_sumsq_clip_adamw_match_torch():
     g = torch.Generator().manual_seed(21)
