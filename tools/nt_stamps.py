@@ -30,7 +30,7 @@ def main():
     M, d, f = 512 * 251, 768, 3072
     UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT
     DH = EPI_MUL_AUX | EPI_COLSUM
-    cases = [('qkv plain', d, 3 * d, 0), ('out plain', d, d, 0), ('ffn_up plain', d, f, 0), ('ffn_down plain', f, d, 0), ('ffn_up GELU', d, f, UP), ('ffn_down dgrad', d, f, DH)]
+    cases = [('qkv plain [L2]', d, 3 * d, 0), ('ffn_down plain [L2]', f, d, 0), ('qkv plain', d, 3 * d, 0), ('out plain', d, d, 0), ('ffn_up plain', d, f, 0), ('ffn_down plain', f, d, 0), ('ffn_up GELU', d, f, UP), ('ffn_down dgrad', d, f, DH)]
     bf, dev = torch.bfloat16, 'cuda'
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
     for name, K, N, epi in cases:
@@ -40,7 +40,12 @@ def main():
         bias = torch.randn(N, device=dev)
         aux = (torch.rand(M, N, device=dev) * 1.2).to(bf) if epi else None
         cso = torch.zeros(N, device=dev) if epi & EPI_COLSUM else None
-        desc = hip.gemm_desc(GEMM_NT, X, W, C, M, N, K, K, K, N, epilogue=epi, bias=bias if epi & EPI_BIAS else None, aux=aux, ldaux=N,
+        lda = ldb = K
+        if name.endswith('[L2]'):       # overlapping rows (row pitch 128 B): 12-24 rows share every line -> operands always hit L2
+            lda = ldb = 64
+            X = torch.randn(M * 64 + K, device=dev).to(bf)
+            W = (torch.randn(N * 64 + K, device=dev) * 0.03).to(bf)
+        desc = hip.gemm_desc(GEMM_NT, X, W, C, M, N, K, lda, ldb, N, epilogue=epi, bias=bias if epi & EPI_BIAS else None, aux=aux, ldaux=N,
                              dropout_p=0.1 if epi & EPI_DROPOUT else 0.0, seed=7, workspace=ws, colsum_out=cso)
         st = torch.cuda.current_stream().cuda_stream
         reps = max(20, int(1.0 / 0.0006))
