@@ -376,6 +376,7 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
         if (d->dtype == ECGVIT_BF16 && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream));   // fused column sums
+        if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, as_stream(stream), 0, 0);
         // generic path: plain GEMM, then the stand-alone column-sum kernel over the stored output
         if (d->workspace_bytes < ecgvit_colsum_workspace(d->M, d->N)) return ECGVIT_EINVAL;
         ecgvit_gemm_desc g = *d;
@@ -386,6 +387,14 @@ extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
     }
     if (d->dtype == ECGVIT_F32) return ecgvit_gemm_f32_launch(d, as_stream(stream));
     if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
+    if (d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) {   // 8-bit operands: the large A . B^T kernel only (no small-shape fallback)
+        if (!d->A || !d->B || !d->C || (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16) return ECGVIT_EINVAL;
+        if ((d->epilogue & ECGVIT_EPI_BIAS) && (!d->bias || reinterpret_cast<uintptr_t>(d->bias) % 16)) return ECGVIT_EINVAL;
+        if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
+        if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
+        if (d->ldc % 8 != 0 || !ecgvit_gemm_nt_applicable(d)) return ECGVIT_EINVAL;
+        return ecgvit_gemm_nt_launch(d, as_stream(stream), 0, 0);
+    }
     return ECGVIT_EINVAL;
 }
 

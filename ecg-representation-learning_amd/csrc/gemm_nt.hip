@@ -29,6 +29,7 @@ constexpr int HALF_BYTES = 16384;
 constexpr int LDS_BYTES = 163840;
 
 typedef __attribute__((address_space(3))) void *lptr_t;
+typedef long i64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
@@ -259,7 +260,7 @@ __device__ unsigned long long g_nt_stamps[256 * 8];
 #define NT_STAMP_T() 0ull
 #endif
 
-template <typename TO, int FL, bool STAMP = false>
+template <typename TO, int FL, bool STAMP = false, int OPS = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems, int ablate) {
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int M = d.M, N = d.N;
@@ -267,8 +268,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const bool late = wm == 1;
-    const int nk = d.K / BK;
-    const int lda2 = (int)d.lda * 2, ldb2 = (int)d.ldb * 2;   // row pitches in bytes
+    // OPS: 0 = bf16 operands; 1 = e4m3 x e4m3, 2 = e4m3 weights x e5m2 activations (input gradients).  An 8-bit K-tile is 128 deep:
+    // the same 128-B image rows, DMA pieces and fragment reads, twice the MFMAs per byte that crosses the CU's memory path
+    constexpr int ES = OPS ? 1 : 2;
+    const int nk = d.K / (128 / ES);
+    const int lda2 = (int)d.lda * ES, ldb2 = (int)d.ldb * ES;   // row pitches in bytes
+    if (d.scale_a) e.alpha *= *d.scale_a;                     // per-tensor scales of 8-bit operands (device scalars)
+    if (d.scale_b) e.alpha *= *d.scale_b;
     const int ntile = tiles_m * tiles_n;
 
     int it = blockIdx.x;
@@ -305,6 +311,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         const int so_ = (soff) + (h) * 128 * ldb2;                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst_, 16, voB0, so_, 0, 0);                                        \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst_ + 1024), 16, voB1, so_, 0, 0);                               \
+    } while (0)
+    // one fragment pair -> accumulator.  8-bit operands: the 16 fragment bytes are two 8-byte k-groups (k = 16c + 8t + j for chunk c, half
+    // t: a permutation of the 128 k's of a row that both operands share), one MFMA each
+#define R_MMA(ACC, WF, XF)                                                                                                       \
+    do {                                                                                                                         \
+        if constexpr (OPS == 0) {                                                                                                \
+            ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF, XF, ACC, 0, 0, 0);                                                 \
+        } else {                                                                                                                 \
+            const i64x2 w_ = __builtin_bit_cast(i64x2, WF), x_ = __builtin_bit_cast(i64x2, XF);                                   \
+            if constexpr (OPS == 1) {                                                                                            \
+                ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_[0], x_[0], ACC, 0, 0, 0);                                    \
+                ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(w_[1], x_[1], ACC, 0, 0, 0);                                    \
+            } else {                                                                                                             \
+                ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w_[0], x_[0], ACC, 0, 0, 0);                                    \
+                ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w_[1], x_[1], ACC, 0, 0, 0);                                    \
+            }                                                                                                                    \
+        }                                                                                                                        \
     } while (0)
 #define R_PHASE_SYNC_A()                                   \
     do {                                                   \
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][s], a[i][s], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) R_MMA(acc[i][j], b0[j][s], a[i][s]);
             R_PHASE_SYNC_B();
             // ---------------- phase 2: rows 0-63 x n-tiles 2,3
 #pragma unroll
@@ -413,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][s], a[i][s], acc[i][2 + j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) R_MMA(acc[i][2 + j], b1[j][s], a[i][s]);
             R_PHASE_SYNC_B();
             // ---------------- phase 3: rows 64-127 x n-tiles 2,3
 #pragma unroll
@@ -428,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j][s], a[i][s], acc[4 + i][2 + j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) R_MMA(acc[4 + i][2 + j], b1[j][s], a[i][s]);
             R_PHASE_SYNC_B();
             // ---------------- phase 4: rows 64-127 x n-tiles 0,1 (no LDS reads); the K-tile's one counted wait: all but A(kt+2) landed
             if (a_issue) {
@@ -448,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j][s], a[i][s], acc[4 + i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) R_MMA(acc[4 + i][j], b0[j][s], a[i][s]);
             R_PHASE_SYNC_B();
             ga = ga == 2 ? 0 : ga + 1;
             gb ^= 1;
@@ -489,6 +512,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #undef R_DMA_A
 #undef R_DMA_B
 #undef R_PHASE_SYNC_A
+#undef R_MMA
 #undef R_PHASE_SYNC_B
 #undef R_ADV_A
 #undef R_ADV_B
@@ -497,10 +521,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 }  // namespace
 
 bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
-    if (d->layout != ECGVIT_GEMM_NT || d->dtype != ECGVIT_BF16) return false;
+    const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
+    if (d->layout != ECGVIT_GEMM_NT || !(d->dtype == ECGVIT_BF16 || f8)) return false;
     if (d->batch1 != 1 || d->batch2 != 1) return false;
-    if (d->M < 2048 || d->N < 128 || d->N % 8 != 0 || d->K % 64 != 0 || d->K < 192) return false;
-    if ((int64_t)d->M * d->lda * 2 + 65536 * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldb * 2 + 65536 * d->ldb >= (1ll << 31)) return false;
+    if (d->M < 2048 || d->N < 128 || d->N % 8 != 0) return false;
+    if (f8 ? (d->K % 128 != 0 || d->K < 384 || d->lda % 16 != 0 || d->ldb % 16 != 0 || d->out_dtype != ECGVIT_BF16) : (d->K % 64 != 0 || d->K < 192)) return false;
+    const int es = f8 ? 1 : 2;
+    if ((int64_t)d->M * d->lda * es + 65536 * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldb * es + 65536 * d->ldb >= (1ll << 31)) return false;
     const int64_t esz = d->out_dtype == ECGVIT_BF16 ? 2 : 4, rows = (int64_t)d->M + 256;   // epilogue offsets are 32-bit byte offsets
     if (rows * d->ldc * esz >= (1ll << 31) || rows * d->ldr * 2 >= (1ll << 31) || rows * d->ldaux * 2 >= (1ll << 31)) return false;
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
@@ -545,7 +572,23 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
         return ECGVIT_OK;
     }
 #endif
-    if (d->out_dtype == ECGVIT_BF16) {
+#define NT_LAUNCH8(FL, OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, FL, false, OPS>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
+    if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
+        switch (fl) {
+            case 0: NT_LAUNCH8(0, 1); break;
+            case F_LIN: NT_LAUNCH8(F_LIN, 1); break;
+            case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_LIN | ECGVIT_EPI_DROPOUT, 1); break;
+            case F_UP: NT_LAUNCH8(F_UP, 1); break;
+            case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT, 1); break;
+            default: NT_LAUNCH8(-1, 1); break;
+        }
+    } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
+        switch (fl) {
+            case 0: NT_LAUNCH8(0, 2); break;
+            case F_DH: NT_LAUNCH8(F_DH, 2); break;
+            default: NT_LAUNCH8(-1, 2); break;
+        }
+    } else if (d->out_dtype == ECGVIT_BF16) {
         switch (fl) {
             case 0: NT_LAUNCH(bf16_t, 0); break;
             case F_LIN: NT_LAUNCH(bf16_t, F_LIN); break;
@@ -560,6 +603,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
         else NT_LAUNCH(float, -1);
     }
 #undef NT_LAUNCH
+#undef NT_LAUNCH8
     ECGVIT_CHECK_LAUNCH();
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         ecgvit_colsum_reduce_launch((const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out, s);

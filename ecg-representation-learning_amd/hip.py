@@ -14,7 +14,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('ECGVIT_HIP_LIB') or os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # env: A/B another build of the same ABI
 
-F32, BF16 = 0, 1
+F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD_AUX, EPI_MUL_AUX = 128, 256
@@ -40,6 +40,7 @@ class GemmDesc(Structure):
         ('bias', c_void_p), ('residual', c_void_p), ('ldr', c_int64), ('aux', c_void_p), ('ldaux', c_int64),
         ('alpha', c_float), ('dropout_p', c_float), ('dropout_seed', c_uint64),
         ('workspace', c_void_p), ('workspace_bytes', c_int64), ('colsum_out', c_void_p), ('tiles_per_workgroup', c_int32),
+        ('scale_a', c_void_p), ('scale_b', c_void_p),
     ]
 
 
@@ -50,6 +51,9 @@ SIGNATURES = {
     'ecgvit_abi_version': (c_int, []),
     'ecgvit_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'ecgvit_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
+    'ecgvit_fp8_amax': (c_int, [_P, _P, _I, _L, _P, _P]),
+    'ecgvit_fp8_quantize': (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P]),
+    'ecgvit_fp8_scale_update': (c_int, [_P, _P, _I, _P, _I, _P]),
     'ecgvit_patch_gather': (c_int, [_P, _P, _I, _I, _I, _I, _L, _I, _P]),
     'ecgvit_patch_gather_transform': (c_int, [_P, _P, _I, _I, _I, _I, _I, _L, _P, _P, _P, _P, _I, _P]),
     'ecgvit_embed_finish': (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _U, _I, _P]),
@@ -139,11 +143,12 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
               alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None):
+              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None, fp8_format=None, scale_a=None, scale_b=None):
     """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
     d = GemmDesc()
-    d.layout, d.dtype, d.out_dtype, d.epilogue = layout, code(A.dtype), code(C.dtype), epilogue
+    d.layout, d.dtype, d.out_dtype, d.epilogue = layout, (fp8_format if fp8_format is not None else code(A.dtype)), code(C.dtype), epilogue
+    d.scale_a, d.scale_b = ptr(scale_a), ptr(scale_b)   # device scalars of 8-bit operands (A, B are uint8 tensors then)
     d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, batch[0], batch[1]
     d.A, d.lda, d.strideA1, d.strideA2 = A.data_ptr() + a_off * A.element_size(), lda, strideA[0], strideA[1]
     d.B, d.ldb, d.strideB1, d.strideB2 = B.data_ptr() + b_off * B.element_size(), ldb, strideB[0], strideB[1]

@@ -35,6 +35,8 @@ extern "C" {
 
 #define ECGVIT_F32 0
 #define ECGVIT_BF16 1
+#define ECGVIT_FP8_E4M3 2 /* OCP e4m3fn, 1 byte: GEMM operands only (ecgvit_gemm A/B, ecgvit_fp8_*)   */
+#define ECGVIT_BF8_E5M2 3 /* OCP e5m2,   1 byte: the A operand of input-gradient products            */
 
 /* library / build identification: "ecgvit-hip gfx950 <abi-version>" */
 const char *ecgvit_version(void);
@@ -67,7 +69,8 @@ int ecgvit_abi_version(void);
 
 typedef struct ecgvit_gemm_desc {
     int32_t layout;    /* ECGVIT_GEMM_*                                             */
-    int32_t dtype;     /* element type of A and B: ECGVIT_F32 | ECGVIT_BF16         */
+    int32_t dtype;     /* element type of A and B: ECGVIT_F32 | ECGVIT_BF16; or ECGVIT_FP8_E4M3 | ECGVIT_BF8_E5M2 = the 8-bit
+                          format of A with B in e4m3 (ECGVIT_GEMM_NT only, K % 128 == 0, lda/ldb % 16 == 0, bf16 output) */
     int32_t out_dtype; /* element type of C, aux, residual                          */
     int32_t epilogue;  /* OR of ECGVIT_EPI_*                                        */
     int32_t M, N, K;
@@ -90,11 +93,27 @@ typedef struct ecgvit_gemm_desc {
                              collectives overlapped with the backward pass) hold CUs, where a static share would leave the
                              workgroups that start late a full share behind (large weight-gradient products then cut three times as many K-slices).
                              A.B^T results are identical either way; the weight-gradient sum order follows the slice count. */
+    const float *scale_a, *scale_b; /* optional device scalars multiplied into alpha: the per-tensor scales of 8-bit operands
+                             (x ~= q * scale), read by the kernel -- no host round trip between the quantise pass and the product */
 } ecgvit_gemm_desc;
 
 int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
 /* bytes of workspace with which the call would use its preferred split-K factor (0 = none needed) */
 int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d);
+
+/* ------------------------------------------------------------------------------------------------
+ * fp8 operand path (BASELINE.json configs[4]; nothing in the reference: its live trainer is f32, models/train.py:197).
+ * Segment form: table[2s] = first element, table[2s+1] = element count of segment s inside x / y (multiples of 8), scale / amax
+ * indexed by s; table == NULL with nseg == 1 means the single segment [0, count).  `count` = the longest segment.
+ * ------------------------------------------------------------------------------------------------ */
+/* amax[s] = max(amax[s], max |x|) over bf16 x */
+int ecgvit_fp8_amax(const void *x, const int64_t *table, int nseg, int64_t count, float *amax, void *stream);
+/* y = saturate(x / scale[s]) in `format` (ECGVIT_FP8_E4M3 | ECGVIT_BF8_E5M2), one byte per element at the same element offsets;
+ * amax_next (optional) accumulates max |x| per segment for the next step's scale (delayed scaling) */
+int ecgvit_fp8_quantize(const void *x, void *y, const int64_t *table, int nseg, int64_t count, int format, const float *scale,
+                        float *amax_next, void *stream);
+/* scale[i] = amax[i] / FORMAT_MAX where amax[i] > 0 (else kept; 1.0 if never set); amax[i] = 0.  formats: per-entry, or NULL = format_all */
+int ecgvit_fp8_scale_update(float *scale, float *amax, int n, const int32_t *formats, int format_all, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * patch embedding front end.  replaces: einops Rearrange('b c (h p1) (w p2) -> b (h w) (p1 p2 c)')
