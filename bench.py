@@ -34,6 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA
 PEAK_F32_TFLOPS = 157.3
 
 CONFIGS = {
@@ -61,14 +62,15 @@ class GemmProbe:
     def __init__(self, hip, layout, out_dtype):
         self.hip, self.layout, self.out_dtype = hip, layout, out_dtype
         self.orig = hip.gemm
-        self.events, self.flops, self.bytes = [], 0.0, 0.0
+        self.events, self.flops, self.bytes, self.n8 = [], 0.0, 0.0, 0
         self.enabled = False
 
     def install(self):
         probe = self
 
         def gemm(layout, A, B, C, M, N, K, *a, **k):
-            hit = (probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and A.dtype == torch.bfloat16
+            f8 = k.get('fp8_format') is not None
+            hit = (probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and (A.dtype == torch.bfloat16 or f8)
                    and K % 64 == 0 and K >= 192 and M >= 2048 and N >= 128)   # = ecgvit_gemm_nt_applicable: the launches of gemm_nt_kernel
             if hit:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -78,7 +80,8 @@ class GemmProbe:
                 e1.record()
                 probe.events.append((e0, e1))
                 probe.flops += 2.0 * M * N * K
-                probe.bytes += 2.0 * (M * K + N * K + M * N)
+                probe.bytes += (1.0 if f8 else 2.0) * (M * K + N * K) + 2.0 * M * N
+                probe.n8 += 1 if f8 else 0
         self.hip.gemm = gemm
         import ecg_representation_learning_amd.engine as eng
         self._eng_hip = eng.hip
@@ -94,7 +97,7 @@ class GemmProbe:
         ms = sum(a.elapsed_time(b) for a, b in self.events)
         n = len(self.events)
         return dict(launches=n, avg_us=1e3 * ms / n, tflops=self.flops / (ms * 1e-3) / 1e12, alg_bytes_per_launch=self.bytes / n,
-                    flops_per_launch=self.flops / n)
+                    flops_per_launch=self.flops / n, launches_8bit=self.n8)
 
 
 def kernel_source_hash():
@@ -193,7 +196,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='base', choices=sorted(CONFIGS))
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'fp8'], help="fp8 = bf16 path with e4m3/e5m2 operands in the block Linears (fp8 MFMA)")
     ap.add_argument('--patch', type=int, default=20)
     ap.add_argument('--length', type=int, default=5000)
     ap.add_argument('--dropout', type=float, default=None, help='override (default: reference config default 0.1)')
@@ -221,7 +224,8 @@ def main():
 
     conf, batch = make_config(E, args.config, args.patch, args.length, args.dropout)
     batch = args.batch or batch
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    dtype = torch.float32 if args.dtype == 'f32' else torch.bfloat16
+    fp8 = args.dtype == 'fp8'
 
     def sync():
         if world > 1:
@@ -232,7 +236,7 @@ def main():
     def timed_run(objective, steps, warmup):
         """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result)"""
         torch.manual_seed(77)  # identical initial weights on every rank (HipTrainStep broadcasts rank 0's anyway)
-        model = E.EcgVit(config=conf, compute_dtype=dtype)
+        model = E.EcgVit(config=conf, compute_dtype=dtype, fp8_linear=fp8)
         if objective == 'masked':
             model = E.MaskedEcgVit(model, mask_ratio=0.5)
         model = model.to(dev).train()
@@ -275,10 +279,12 @@ def main():
             return None
         margs = argparse.Namespace(**{**vars(args), 'objective': objective})
         traffic, source = pmc_traffic('gemm_nt', margs)
+        peak = PEAK_FP8_TFLOPS if r['launches_8bit'] else PEAK_BF16_TFLOPS
         return {
             'kernel': 'gemm_nt_kernel<bf16 out> (persistent quadrant-phased 256x256x64 LDS-DMA GEMM with a register-direct epilogue, A . B^T: '
-                      'the Linear forward launches QKV / attn-out / FFN-up / FFN-down and, against the transposed weight shadows, their input-gradient launches)',
-            'bound': 'mfma', 'achieved': r['tflops'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': r['tflops'] / PEAK_BF16_TFLOPS,
+                      'the Linear forward launches QKV / attn-out / FFN-up / FFN-down and, against the transposed weight shadows, their input-gradient launches'
+                      + ('; e4m3 / e5m2 operands on the block-scaled fp8 MFMA, K-tile 128 deep' if r['launches_8bit'] else '') + ')',
+            'bound': 'mfma', 'achieved': r['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': r['tflops'] / peak,
             'traffic': traffic, 'traffic_source': source, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
             'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
         }
@@ -305,7 +311,8 @@ def main():
             else f'12-lead ECG records/sec train step, EcgVit-{args.config}',
             'value': value, 'unit': 'records/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
+            'dtype': args.dtype if not fp8 else 'fp8 (e4m3 / e5m2 operands in the block Linears\' forward and input-gradient GEMMs; bf16 weight gradients, attention, LayerNorm)',
+            'data': 'synthetic',
             'config': {
                 'workload': f'EcgVit-{args.config} ' + ('masked-patch pre-train step (SimMIM-style, 50 % of patches masked, L1 recon; fwd+loss+bwd+clip+AdamW'
                             if args.objective == 'masked' else 'supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW') + (

@@ -30,6 +30,8 @@ constexpr int LDS_BYTES = 163840;
 
 typedef __attribute__((address_space(3))) void *lptr_t;
 typedef long i64x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const bool late = wm == 1;
-    // OPS: 0 = bf16 operands; 1 = e4m3 x e4m3, 2 = e4m3 weights x e5m2 activations (input gradients).  An 8-bit K-tile is 128 deep:
+    // OPS: 0 = bf16 operands; 1 / 3 = e4m3 x e4m3, 2 / 4 = e4m3 weights x e5m2 activations (input gradients), on the plain fp8 MFMA
+    // (bf16 rate) / on the block-scaled MFMA with unit scales (twice the rate: what ships).  An 8-bit K-tile is 128 deep:
     // the same 128-B image rows, DMA pieces and fragment reads, twice the MFMAs per byte that crosses the CU's memory path
     constexpr int ES = OPS ? 1 : 2;
     const int nk = d.K / (128 / ES);
@@ -326,6 +329,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             } else {                                                                                                             \
                 ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w_[0], x_[0], ACC, 0, 0, 0);                                    \
                 ACC = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(w_[1], x_[1], ACC, 0, 0, 0);                                    \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    } while (0)
+    // one 64 x 32 output quadrant of the wave tile x one K-tile.  OPS 3 / 4: the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with every
+    // block scale 2^0 (E8M0 0x7F) -- plain e4m3 x e4m3 / e5m2 products at twice the bf16 MFMA rate; a lane's 32 operand bytes are its
+    // two 16-B fragment reads (chunks q and 4+q of the 128-B row: again one k-permutation shared by both operands)
+#define R_QUAD(IO, JO, BF)                                                                                                       \
+    do {                                                                                                                         \
+        if constexpr (OPS <= 2) {                                                                                                \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) R_MMA(acc[IO + i][JO + j], BF[j][s], a[i][s]);                     \
+        } else {                                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                        \
+                const i32x4 w0_ = __builtin_bit_cast(i32x4, BF[j][0]), w1_ = __builtin_bit_cast(i32x4, BF[j][1]);                \
+                const i32x4 x0_ = __builtin_bit_cast(i32x4, a[i][0]), x1_ = __builtin_bit_cast(i32x4, a[i][1]);                  \
+                const i32x8 w_ = {w0_[0], w0_[1], w0_[2], w0_[3], w1_[0], w1_[1], w1_[2], w1_[3]};                               \
+                const i32x8 x_ = {x0_[0], x0_[1], x0_[2], x0_[3], x1_[0], x1_[1], x1_[2], x1_[3]};                               \
+                acc[IO + i][JO + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w_, x_, acc[IO + i][JO + j], 0, OPS == 4 ? 1 : 0, 0,   \
+                                                                                       0x7F7F7F7F, 0, 0x7F7F7F7F);               \
             }                                                                                                                    \
         }                                                                                                                        \
     } while (0)
@@ -417,12 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
             if (b_issue) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
             R_PHASE_SYNC_A();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) R_MMA(acc[i][j], b0[j][s], a[i][s]);
+            R_QUAD(0, 0, b0);
             R_PHASE_SYNC_B();
             // ---------------- phase 2: rows 0-63 x n-tiles 2,3
 #pragma unroll
@@ -431,12 +448,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
                 for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (s * 64)));
             if (b_issue) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
             R_PHASE_SYNC_A();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) R_MMA(acc[i][2 + j], b1[j][s], a[i][s]);
+            R_QUAD(0, 2, b1);
             R_PHASE_SYNC_B();
             // ---------------- phase 3: rows 64-127 x n-tiles 2,3
 #pragma unroll
@@ -446,12 +458,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             const bool a_issue = a_ok && !pre_k;
             if (a_issue) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
             R_PHASE_SYNC_A();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) R_MMA(acc[4 + i][2 + j], b1[j][s], a[i][s]);
+            R_QUAD(4, 2, b1);
             R_PHASE_SYNC_B();
             // ---------------- phase 4: rows 64-127 x n-tiles 0,1 (no LDS reads); the K-tile's one counted wait: all but A(kt+2) landed
             if (a_issue) {
@@ -466,12 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             R_PHASE_SYNC_A();
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) R_MMA(acc[4 + i][j], b0[j][s], a[i][s]);
+            R_QUAD(4, 0, b0);
             R_PHASE_SYNC_B();
             ga = ga == 2 ? 0 : ga + 1;
             gb ^= 1;
@@ -513,6 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #undef R_DMA_B
 #undef R_PHASE_SYNC_A
 #undef R_MMA
+#undef R_QUAD
 #undef R_PHASE_SYNC_B
 #undef R_ADV_A
 #undef R_ADV_B
@@ -573,20 +576,23 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     }
 #endif
 #define NT_LAUNCH8(FL, OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, FL, false, OPS>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
+#ifdef ECGVIT_TOOLS
+    if ((diag & 64) && fl == 0 && d->dtype == ECGVIT_FP8_E4M3) { NT_LAUNCH8(0, 1); ECGVIT_CHECK_LAUNCH(); return ECGVIT_OK; }   // plain fp8 MFMA (A/B)
+#endif
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
         switch (fl) {
-            case 0: NT_LAUNCH8(0, 1); break;
-            case F_LIN: NT_LAUNCH8(F_LIN, 1); break;
-            case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_LIN | ECGVIT_EPI_DROPOUT, 1); break;
-            case F_UP: NT_LAUNCH8(F_UP, 1); break;
-            case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT, 1); break;
-            default: NT_LAUNCH8(-1, 1); break;
+            case 0: NT_LAUNCH8(0, 3); break;
+            case F_LIN: NT_LAUNCH8(F_LIN, 3); break;
+            case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_LIN | ECGVIT_EPI_DROPOUT, 3); break;
+            case F_UP: NT_LAUNCH8(F_UP, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT, 3); break;
+            default: NT_LAUNCH8(-1, 3); break;
         }
     } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
         switch (fl) {
-            case 0: NT_LAUNCH8(0, 2); break;
-            case F_DH: NT_LAUNCH8(F_DH, 2); break;
-            default: NT_LAUNCH8(-1, 2); break;
+            case 0: NT_LAUNCH8(0, 4); break;
+            case F_DH: NT_LAUNCH8(F_DH, 4); break;
+            default: NT_LAUNCH8(-1, 4); break;
         }
     } else if (d->out_dtype == ECGVIT_BF16) {
         switch (fl) {

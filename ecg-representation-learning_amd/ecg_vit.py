@@ -241,10 +241,13 @@ class EcgVit(nn.Module):
     reference ecg_vit.py:95-149.  Extra (keyword-only in spirit) argument `compute_dtype`:
       torch.float32  -- parity path (exact-f32 MFMA; reproduces the reference's CPU numbers to ~1e-6)
       torch.bfloat16 -- throughput path (bf16 MFMA GEMMs + fused attention, f32 accumulate / statistics / master weights)
+    `fp8_linear=True` (with bf16): the block Linears' forward and input-gradient products run on the CDNA4 fp8 MFMA with per-tensor
+    scaled e4m3 / e5m2 operands (BASELINE.json configs[4]); master weights, optimiser, weight gradients, attention stay as in bf16.
     """
 
-    def __init__(self, num_class: int = 71, config=None, loss_reduction: str = 'mean', compute_dtype=torch.float32):
+    def __init__(self, num_class: int = 71, config=None, loss_reduction: str = 'mean', compute_dtype=torch.float32, fp8_linear=False):
         super().__init__()
+        self.fp8_linear = bool(fp8_linear)   # bf16 path with e4m3 / e5m2 operands in the block Linears' forward and input-gradient products
         config = config if config is not None else EcgVitConfig()
         hd_sz, n_head = config.hidden_size, config.num_attention_heads
         assert hd_sz % n_head == 0
@@ -349,7 +352,7 @@ class EcgVit(nn.Module):
             self._eng = VitEngine(C=c.num_channels, L=c.max_signal_length, P=c.patch_size, d=c.hidden_size,
                                   h=c.num_attention_heads, f=c.intermediate_size, Ly=c.num_hidden_layers, K=self.num_class,
                                   p_hidden=c.hidden_dropout_prob, p_emb=c.attention_probs_dropout_prob,
-                                  dtype=self.compute_dtype, layout=self._layout)
+                                  dtype=self.compute_dtype, layout=self._layout, fp8_linear=self.fp8_linear)
             self._wlow_t = self._tr_table = None
             if self.compute_dtype == torch.bfloat16:
                 self._wlow = torch.empty(self._layout.total, dtype=torch.bfloat16, device=self._pflat.device)
@@ -378,6 +381,8 @@ class EcgVit(nn.Module):
         if getattr(self, '_wlow_t', None) is not None:
             hip.check(hip.lib().ecgvit_transpose_bf16_batched(self._wlow.data_ptr(), self._wlow_t.data_ptr(), self._tr_table.data_ptr(),
                                                               self._tr_nmat, self._tr_tiles, hip.stream()), 'transpose_bf16_batched')
+        if self._eng is not None and getattr(self._eng, 'fp8', False):
+            self._eng.refresh_fp8_weights()
 
     def set_input_transform(self, transform):
         """f2: give the model RAW records; Normalize / TimeEndPad / TimeOut run fused inside the patch-embed load

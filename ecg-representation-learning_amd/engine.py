@@ -26,8 +26,8 @@ def _align(n, a=8):
 
 
 class ParamLayout:
-    """name -> (offset, shape) inside one flat f32 buffer; every tensor starts on a 32-B boundary so the same
-    offsets address the bf16 shadow on 16-B boundaries (vector loads everywhere)."""
+    """name -> (offset, shape) inside one flat f32 buffer; every tensor starts on a 64-B boundary so the same
+    offsets address the bf16 shadow on 32-B and the 8-bit shadows on 16-B boundaries (vector loads everywhere)."""
 
     def __init__(self, named_shapes):
         self.entries = OrderedDict()
@@ -37,7 +37,7 @@ class ParamLayout:
             for s in shape:
                 n *= s
             self.entries[name] = (off, tuple(shape), n)
-            off = _align(off + n)
+            off = _align(off + n, 16)
         self.total = off
 
     def view(self, flat, name):
@@ -52,7 +52,7 @@ class ParamLayout:
         lo, hi = min(a for a, _ in sel), max(b for _, b in sel)
         inside = [n for n, (o, _, c) in self.entries.items() if lo <= o < hi]
         assert all(pred(n) for n in inside), 'bucket is not contiguous in the flat layout'
-        return lo, _align(hi)
+        return lo, _align(hi, 16)
 
     def buckets_in_ready_order(self, n_layers):
         """gradient buckets in the order the backward pass completes them: head, layers L-1..0, then embedding (+ extras)"""
@@ -70,7 +70,7 @@ class VitEngine:
     """Forward / backward of EcgVit for one activation dtype (torch.float32 = parity path, torch.bfloat16 =
     throughput path). Caller provides the flat buffers; all activations are allocated here, once per batch size."""
 
-    def __init__(self, *, C, L, P, d, h, f, Ly, K, p_hidden, p_emb, dtype, layout: ParamLayout):
+    def __init__(self, *, C, L, P, d, h, f, Ly, K, p_hidden, p_emb, dtype, layout: ParamLayout, fp8_linear=False):
         assert L % P == 0, 'Image dimensions must be divisible by the patch size.'  # vit_pytorch's own assertion text
         self.C, self.L, self.P, self.d, self.h, self.f, self.Ly, self.K = C, L, P, d, h, f, Ly, K
         self.n = L // P
@@ -93,6 +93,14 @@ class VitEngine:
                 raise ValueError(f'bf16 fused attention needs head dim 64 (got {self.dh}); use dtype=torch.float32')
             if self.N > 512:
                 raise ValueError(f'bf16 fused attention covers <= 512 tokens (got {self.N}); use dtype=torch.float32')
+        # fp8 Linear operands (BASELINE.json configs[4]): the four block Linears' forward and input-gradient products take e4m3 / e5m2
+        # operands (per-tensor scales, delayed for activations and gradients); weight gradients, attention, LayerNorm stay bf16
+        self.fp8 = bool(fp8_linear)
+        if self.fp8:
+            if dtype != torch.bfloat16:
+                raise ValueError('fp8_linear needs the bf16 engine (compute_dtype=torch.bfloat16)')
+            if d % 128 or f % 128:
+                raise ValueError(f'fp8_linear needs hidden_size and intermediate_size to be multiples of 128 (got d={d}, f={f})')
         self.B = None
         self._alloc_key = None
         self.T = self.N
@@ -121,6 +129,68 @@ class VitEngine:
         else:
             self.W = self.P32
         self.device = pflat.device
+        if self.fp8:
+            assert wlow_t is not None, 'fp8_linear runs the input gradients against the transposed weight shadows'
+            names = self.transposed_weight_names()
+            assert len(names) == 4 * self.Ly, 'fp8_linear: every block Linear must be large enough for the 256^2 kernel'
+            self._wlow, self._wlow_t = wlow, wlow_t
+            self.w8 = torch.zeros(lay.total, dtype=torch.uint8, device=self.device)
+            self.w8t = torch.zeros(lay.total, dtype=torch.uint8, device=self.device)
+            self.w8_index = {k: i for i, k in enumerate(names)}
+            self.w8_table = torch.tensor([[lay.entries[k][0], lay.entries[k][2]] for k in names], dtype=torch.int64, device=self.device)
+            self.w8_count = max(lay.entries[k][2] for k in names)
+            self.w8_scale = torch.zeros(len(names), dtype=torch.float32, device=self.device)
+            self.w8_amax = torch.zeros(len(names), dtype=torch.float32, device=self.device)
+            self.W8, self.WT8 = {}, {}
+            for k in names:
+                off, (r, c), n = lay.entries[k]
+                self.W8[k] = self.w8[off:off + n].view(r, c)
+                self.WT8[k] = self.w8t[off:off + n].view(c, r)
+            # activation / gradient sites, 8 per layer: e4m3 xn1, attn, xn2, hact ; e5m2 dY(ffn-down), dh, dY(out), dqkv
+            ns = 8 * self.Ly
+            self.f8_scale = torch.zeros(ns, dtype=torch.float32, device=self.device)
+            self.f8_amax = torch.zeros(ns, dtype=torch.float32, device=self.device)
+            self.f8_fmt = torch.tensor(([hip.FP8_E4M3] * 4 + [hip.BF8_E5M2] * 4) * self.Ly, dtype=torch.int32, device=self.device)
+            self._f8_seen = set()
+
+    # ---------------------------------------------------------------- fp8 operand path
+    def refresh_fp8_weights(self):
+        """e4m3 shadows of the block Linears' weights and of their transposes, one scale per matrix from its current amax: three
+        launches over the flat bf16 shadows (call after the optimiser rewrote them)"""
+        l, st = lib(), stream()
+        nm = len(self.w8_index)
+        check(l.ecgvit_fp8_amax(ptr(self._wlow), ptr(self.w8_table), nm, self.w8_count, ptr(self.w8_amax), st), 'fp8_amax')
+        check(l.ecgvit_fp8_scale_update(ptr(self.w8_scale), ptr(self.w8_amax), nm, None, hip.FP8_E4M3, st), 'fp8_scale_update')
+        for src, dst in ((self._wlow, self.w8), (self._wlow_t, self.w8t)):
+            check(l.ecgvit_fp8_quantize(ptr(src), ptr(dst), ptr(self.w8_table), nm, self.w8_count, hip.FP8_E4M3, ptr(self.w8_scale), None, st),
+                  'fp8_quantize')
+
+    def fp8_begin_step(self):
+        """delayed scaling: the scales of this pass come from the amax the previous pass's quantise kernels accumulated"""
+        if self._f8_seen:
+            check(lib().ecgvit_fp8_scale_update(ptr(self.f8_scale), ptr(self.f8_amax), self.f8_scale.numel(), ptr(self.f8_fmt), 0, stream()),
+                  'fp8_scale_update')
+
+    def _quant(self, site, x, count):
+        """x (bf16, `count` elements) -> the shared 8-bit scratch in the site's format; returns (scratch view, scale pointer tensor)"""
+        l, st = lib(), stream()
+        sc, am = self.f8_scale[site:site + 1], self.f8_amax[site:site + 1]
+        fmt = hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2
+        if site not in self._f8_seen:   # first use: no history yet -> scale from this tensor's own amax (one extra read)
+            check(l.ecgvit_fp8_amax(ptr(x), None, 1, count, ptr(am), st), 'fp8_amax')
+            check(l.ecgvit_fp8_scale_update(ptr(sc), ptr(am), 1, None, fmt, st), 'fp8_scale_update')
+            self._f8_seen.add(site)
+        q = self.act['q8'][:count]
+        check(l.ecgvit_fp8_quantize(ptr(x), ptr(q), None, 1, count, fmt, ptr(sc), ptr(am), st), 'fp8_quantize')
+        return q, sc
+
+    def _linear(self, site, A, name, C, M, N, K, **kw):
+        """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow"""
+        if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
+            return hip.gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
+        q, sc = self._quant(site, A, M * K)
+        mi = self.w8_index[name]
+        hip.gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
 
     def transposed_weight_names(self):
         """Linear weights of the transformer blocks whose dgrad is large enough for the 256^2 forward kernel (K % 64 == 0, N >= 256)"""
@@ -144,8 +214,13 @@ class VitEngine:
             return None, 0, 0
         return torch.tensor(rows_, dtype=torch.int64, device=device), len(rows_), t
 
-    def _dgrad(self, dY, name, dX, M, kin, nout, **kw):
+    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, **kw):
         """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one"""
+        if self.fp8 and site is not None and M >= 2048 and name in self.w8_index:
+            q, sc = self._quant(site, dY, M * nout)
+            mi = self.w8_index[name]
+            return hip.gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
+                            scale_b=self.w8_scale[mi:mi + 1], **kw)
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
             hip.gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
@@ -192,6 +267,8 @@ class VitEngine:
                      target=e(B * m, self.CP), dpred=e(B * m, self.CP), drows=e(B * m, d), dmasked=e(Mp, d),
                      mloss=e(1, dt=torch.float32), l1part=e(1024, dt=torch.float32))
         a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
+        if self.fp8:
+            a['q8'] = torch.empty(M * max(f, 3 * d), device=dev, dtype=torch.uint8)   # one quantised operand at a time
         self.act, self.B = a, B
 
     # ---------------------------------------------------------------- small launch helpers
@@ -251,24 +328,24 @@ class VitEngine:
             s0 = seed + 100 * (i + 1)
             # a6/a7: PreNorm(Attention)
             self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M)
-            hip.gemm(GEMM_NT, L['xn1'], W[lp + '0.fn.to_qkv.weight'], L['qkv'], M, 3 * d, d, d, d, 3 * d)
+            self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
                                              T, st), 'attention_fwd')
             else:
                 self._attn_fwd_f32(L, B, ph, s0 + 1)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            hip.gemm(GEMM_NT, L['attn'], W[lp + '0.fn.to_out.0.weight'], L['x1'], M, d, d, d, d, d, epilogue=epi,
+            self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, epilogue=epi,
                      bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
             # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
             self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M)
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
-            hip.gemm(GEMM_NT, L['xn2'], W[lp + '1.fn.net.0.weight'], L['hact'], M, f, d, d, d, f, epilogue=epi,
+            self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, epilogue=epi,
                      bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            hip.gemm(GEMM_NT, L['hact'], W[lp + '1.fn.net.3.weight'], L['x2'], M, d, f, f, f, d, epilogue=epi,
+            self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, epilogue=epi,
                      bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
             X = L['x2']
         return X
@@ -288,6 +365,8 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False, training=training)
+        if self.fp8:
+            self.fp8_begin_step()
         pre = 'vit.'
         self._patch_embed(x, B)
         # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout
@@ -320,6 +399,8 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m, training=training)
+        if self.fp8:
+            self.fp8_begin_step()
         self._patch_embed(x, B)
         check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),
                                          ptr(idx), ptr(a['x0']), ptr(a['flag']), B, n, m, d, T, st), 'mask_embed_finish')
@@ -467,10 +548,10 @@ class VitEngine:
                 epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
-            self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, epilogue=epi, aux=L['hpre'], ldaux=f,
+            self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, epilogue=epi, aux=L['hpre'], ldaux=f,
                         dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
-            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f)
+            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5)
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
             self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
                                G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2)
@@ -478,14 +559,14 @@ class VitEngine:
             dY = a['dxm'] if ph > 0 else dX
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
-            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d)
+            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
                                              dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
             else:
                 self._attn_bwd_f32(L, B, ph, s0 + 1)
             self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M)
-            self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d)
+            self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d, site=8 * i + 7)
             if i > 0:
                 # LN1 backward; its output feeds layer i-1's FFN-down site (mask seed of layer i-1, bias net.3.bias)
                 lq = f'{pre}transformer.layers.{i - 1}.'

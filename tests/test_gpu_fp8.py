@@ -106,3 +106,61 @@ def test_gemm_8bit_epilogues():
              epilogue=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX, bias=bias, aux=aux, ldaux=N)
     pre = (A.float() @ B.float().t()) * 0.25 + bias
     assert rel_err(C, torch.nn.functional.gelu(pre)) < 4e-3
+
+
+def test_model_fp8_linear_vs_bf16_path():
+    """EcgVit-base layer shape, 2 layers, 12 x 5000 / patch 20: the fp8 Linear path against the bf16 path on the same weights and batch
+    (dropout 0).  Tolerances: e4m3 has 3 mantissa bits (2^-4 relative per element, averaged down by the K = 768..3072 sums): loss within
+    3 % relative, total gradient cosine >= 0.97, every tensor's >= 0.90; then three fused steps stay finite and reduce the loss."""
+    from oracle import vit_oracle as O
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                          hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(5)
+    m16 = E.EcgVit(config=conf, compute_dtype=BF16).cuda().train()
+    m8 = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True)
+    m8.load_state_dict(m16.state_dict())
+    m8.cuda().train()
+    x, y = O.synthetic_batch(12, length=5000, seed=5)     # 12 x 251 = 3012 token rows: above the 8-bit kernel's 2048-row floor
+    x, y = x.cuda(), y.cuda()
+    o16 = m16(sample_values=x, labels=y)
+    o8 = m8(sample_values=x, labels=y)
+    assert len(m8._engine()._f8_seen) == 8, 'the 8-bit Linear path did not run'    # 4 forward sites x 2 layers
+    assert torch.isfinite(o8.logits).all()
+    assert abs(float(o8.loss) - float(o16.loss)) / float(o16.loss) < 3e-2
+    o16.loss.backward(); o8.loss.backward()
+    assert len(m8._engine()._f8_seen) == 16                                             # + 4 gradient sites x 2 layers
+    g16 = torch.cat([p.grad.flatten() for p in m16.parameters()]).double()
+    g8 = torch.cat([p.grad.flatten() for p in m8.parameters()]).double()
+    assert torch.isfinite(g8).all()
+    cos = float((g16 @ g8) / (g16.norm() * g8.norm()))
+    assert cos > 0.97, cos
+    for (k, p), (_, q) in zip(m8.named_parameters(), m16.named_parameters()):
+        c = float((p.grad.double().flatten() @ q.grad.double().flatten()) / (p.grad.double().norm() * q.grad.double().norm() + 1e-30))
+        assert c > 0.90, (k, c)
+    # second forward: delayed scales (from the first pass's amax) instead of the first-use amax pass -- same result to fp8 noise
+    o8b = m8(sample_values=x, labels=y)
+    assert abs(float(o8b.loss) - float(o8.loss)) / float(o8.loss) < 1e-2
+    step = E.HipTrainStep(m8, E.get_train_args(dict(train_batch_size=12, num_train_epoch=1, warmup_ratio=0.0), n_train=12 * 20))
+    losses = [float(step.step(x, y)[0]) for _ in range(4)]
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+def test_full_large_fp8_configuration_properties():
+    """BASELINE.json configs[4] on one GPU: EcgVit-large, patch 10 (501 tokens), fp8 Linear operands, dropout 0.1, 64 records:
+    finite, bit-identical rerun under a pinned seed, a falling loss over three fused steps"""
+    conf = E.EcgVitConfig.from_defined('ecg-vit-large')
+    conf.max_signal_length, conf.patch_size = 5000, 10
+    torch.manual_seed(77)
+    m = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True).cuda().train()
+    x, y = E.workload.synthetic_batch(64, length=5000, seed=77)
+    x, y = x.cuda(), y.cuda()
+    eng = m._engine()
+    eng.forward(x, y, None, training=True, seed=1, want_mean=True)                 # settles the first-use scales
+    la, _, ma = (t.clone() for t in eng.forward(x, y, None, training=True, seed=4711, want_mean=True))
+    eng.f8_amax.zero_()                                                            # same scales for the rerun
+    lb, _, mb = (t.clone() for t in eng.forward(x, y, None, training=True, seed=4711, want_mean=True))
+    assert torch.isfinite(la).all() and torch.equal(la, lb) and torch.equal(ma, mb)
+    step = E.HipTrainStep(m, E.get_train_args(dict(train_batch_size=64, num_train_epoch=1, warmup_ratio=0.0), n_train=64 * 20))
+    losses = [float(step.step(x, y)[0]) for _ in range(3)]
+    step.finish()
+    assert all(l == l and abs(l) < 1e4 for l in losses) and losses[2] < losses[0], losses
