@@ -16,7 +16,7 @@ __device__ __forceinline__ void wave_atomic_max(float *dst, float v) {
     if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned int *>(dst), __float_as_uint(v));   // non-negative floats order as integers
 }
 
-// segments: table[2*s] = first element, table[2*s+1] = element count (both multiples of 8) of segment s = blockIdx.y; a null table = one
+// segments: table[2*s] = first element (multiple of 16), table[2*s+1] = element count (multiple of 8) of segment s = blockIdx.y; a null table = one
 // segment (off0, n0).  amax[s] = max(amax[s], max |x|).
 __global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16_t *__restrict__ x, const int64_t *__restrict__ table, int64_t off0, int64_t n0,
                                                        float *__restrict__ amax) {
@@ -41,8 +41,7 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const bf16_t *__restr
     const float inv = sc > 0.f ? 1.0f / sc : 0.f;
     constexpr float MX = FMT == ECGVIT_BF8_E5M2 ? BF8_E5M2_MAX : FP8_E4M3_MAX;
     float m = 0.f;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * 256 * 8) {
-        const Vec16<bf16_t> v = ld16(x + off + i);
+    auto q8 = [&](const Vec16<bf16_t> &v) {   // 8 bf16 -> 8 bytes
         float f[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -60,7 +59,19 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const bf16_t *__restr
         }
         u32x2 o;
         o[0] = (uint32_t)w0; o[1] = (uint32_t)w1;
-        *reinterpret_cast<u32x2 *>(y + off + i) = o;
+        return o;
+    };
+    // 16 elements per lane and step: two 16-B loads, one 16-B store (an 8-element tail, if any, goes as one 8-B store)
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16; i < n; i += (int64_t)gridDim.x * 256 * 16) {
+        if (i + 16 <= n) {
+            const Vec16<bf16_t> v0 = ld16(x + off + i), v1 = ld16(x + off + i + 8);
+            const u32x2 a = q8(v0), b = q8(v1);
+            u32x4 o;
+            o[0] = a[0]; o[1] = a[1]; o[2] = b[0]; o[3] = b[1];
+            *reinterpret_cast<u32x4 *>(y + off + i) = o;
+        } else {
+            *reinterpret_cast<u32x2 *>(y + off + i) = q8(ld16(x + off + i));
+        }
     }
     if (amax_next) wave_atomic_max(amax_next + s, m);
 }
@@ -75,7 +86,7 @@ __global__ void fp8_scale_update_kernel(float *__restrict__ scale, float *__rest
 }
 
 inline dim3 seg_grid(int64_t n_max, int nseg) {
-    const int64_t b = (n_max / 8 + 255) / 256;
+    const int64_t b = (n_max / 16 + 255) / 256;
     return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(b, nseg > 1 ? 256 : 4096)), (unsigned)nseg);
 }
 

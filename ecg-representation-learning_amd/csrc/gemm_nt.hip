@@ -71,14 +71,16 @@ __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast
 // operations: `off` is the byte offset of (m, n) in C scaled per buffer by the caller, 0x80000000 for a masked lane -- beyond
 // every descriptor's num_records, so loads return zero and stores are dropped, and the body needs no exec-mask branch.
 struct NtBufs {
-    __amdgpu_buffer_rsrc_t c, res, aux;
-    int ldc2, ldr2, ldx2;   // row pitches in bytes
+    __amdgpu_buffer_rsrc_t c, res, aux, q8;
+    int ldc2, ldr2, ldx2, ldq;   // row pitches in bytes
+    float q8_inv;                // 1 / scale of the 8-bit output copy (ECGVIT_EPI_QUANT_OUT)
+    int q8_bf8;                  // its format: 0 = e4m3, 1 = e5m2
 };
 constexpr uint32_t NT_OOB = 0x80000000u;
 
 template <typename TO, int FL>
 __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, const NtBufs &bf, const EpiParams &e,
-                                        const u32x4 &res, const u32x4 &auxin, float *cs8) {
+                                        const u32x4 &res, const u32x4 &auxin, float *cs8, float &qmax) {
     if (e.alpha != 1.f) {   // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
@@ -140,6 +142,29 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cs8[2 * k] += ok ? bf16_lo(out[k]) : 0.f; cs8[2 * k + 1] += ok ? bf16_hi(out[k]) : 0.f; }
         }
+        if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // the 8-bit copy of the values as stored (what a separate quantise pass would read back)
+            float f[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { f[2 * k] = bf16_lo(out[k]); f[2 * k + 1] = bf16_hi(out[k]); }
+            if (ok) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) qmax = fmaxf(qmax, fabsf(f[k]));
+            }
+            const float mx = bf.q8_bf8 ? 57344.f : 448.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = __builtin_amdgcn_fmed3f(f[k] * bf.q8_inv, -mx, mx);
+            int w0 = 0, w1 = 0;
+            if (bf.q8_bf8) {
+                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+            } else {
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            }
+            u32x2 q;
+            q[0] = (uint32_t)w0; q[1] = (uint32_t)w1;
+            __builtin_amdgcn_raw_buffer_store_b64(q, bf.q8, ok ? m * (uint32_t)bf.ldq + ncol : NT_OOB, 0, 0);
+        }
     } else {
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
         if (NT_HAS(ECGVIT_EPI_ACCUM)) {
@@ -179,6 +204,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
     float cs[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) cs[k] = 0.f;
+    float qmax = 0.f;
     const uint32_t mrow = (uint32_t)(m0 + wm * 128 + c);
     constexpr bool kBf = sizeof(TO) == 2;
     constexpr bool kLight = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
@@ -205,8 +231,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
             const uint32_t m = mrow + 16 * i;
             const bool mok = (int)m < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, R[i][0], X[i][0], cs);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, R[i][1], X[i][1], cs + 8);
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, R[i][0], X[i][0], cs, qmax);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, R[i][1], X[i][1], cs + 8, qmax);
         }
     } else {
         // heavy bodies must exist ONCE in the instruction stream (I-cache): rolled loop, only the accumulator pick is a switch;
@@ -227,9 +253,13 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #undef NT_PICK
             const uint32_t m = mrow + 16 * i;
             const bool mok = (int)m < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, r0, a0, cs);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, r1, a1, cs + 8);
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, r0, a0, cs, qmax);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, r1, a1, cs + 8, qmax);
         }
+    }
+    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // one atomic max per wave and tile (non-negative floats order as integers)
+        qmax = wave_max(qmax);
+        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(d.q8_amax), __float_as_uint(qmax));
     }
     if (NT_HAS(ECGVIT_EPI_COLSUM)) {
         // lanes with equal (lane >> 4) hold the same 16 columns: fold the 16 rows, one partial row per (tile row, wm)
@@ -290,6 +320,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (STAMP && (ablate & 1)) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1 (diagnostics): stores dropped
     bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
     bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
+    bf.ldq = (int)d.ldq8;
+    bf.q8 = __builtin_amdgcn_make_buffer_rsrc(d.q8_out, 0, d.q8_out ? (uint32_t)((int64_t)M * bf.ldq) : 0u, 0x00020000);
+    bf.q8_bf8 = d.q8_format == ECGVIT_BF8_E5M2;
+    bf.q8_inv = 0.f;
+    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) { const float qs = *d.q8_scale; bf.q8_inv = qs > 0.f ? 1.0f / qs : 0.f; }
     // this wave's two DMA pieces of a half-tile: rows 16*wave + {0..7}, {8..15}; LDS chunk p of row r holds source chunk p ^ f(r)
     const int r0 = 16 * wave + (lane >> 3), r1 = r0 + 8, p = lane & 7;
     const int voA0 = r0 * lda2 + ((p ^ ((r0 >> 1) & 7)) << 4), voA1 = r1 * lda2 + ((p ^ ((r1 >> 1) & 7)) << 4);
@@ -533,6 +568,11 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     if ((int64_t)d->M * d->lda * es + 65536 * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldb * es + 65536 * d->ldb >= (1ll << 31)) return false;
     const int64_t esz = d->out_dtype == ECGVIT_BF16 ? 2 : 4, rows = (int64_t)d->M + 256;   // epilogue offsets are 32-bit byte offsets
     if (rows * d->ldc * esz >= (1ll << 31) || rows * d->ldr * 2 >= (1ll << 31) || rows * d->ldaux * 2 >= (1ll << 31)) return false;
+    if (d->epilogue & ECGVIT_EPI_QUANT_OUT) {
+        if (!f8 || !d->q8_out || !d->q8_scale || !d->q8_amax || d->ldq8 % 8 || reinterpret_cast<uintptr_t>(d->q8_out) % 8 ||
+            (d->q8_format != ECGVIT_FP8_E4M3 && d->q8_format != ECGVIT_BF8_E5M2) || rows * d->ldq8 >= (1ll << 31))
+            return false;
+    }
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (d->out_dtype != ECGVIT_BF16 || !d->workspace || !d->colsum_out ||
             d->workspace_bytes < (int64_t)8 * ((d->M + BM - 1) / BM) * d->N)
@@ -586,12 +626,15 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_LIN | ECGVIT_EPI_DROPOUT, 3); break;
             case F_UP: NT_LAUNCH8(F_UP, 3); break;
             case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT, 3); break;
+            case F_UP | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT, 3); break;
             default: NT_LAUNCH8(-1, 3); break;
         }
     } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
         switch (fl) {
             case 0: NT_LAUNCH8(0, 4); break;
             case F_DH: NT_LAUNCH8(F_DH, 4); break;
+            case F_DH | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT, 4); break;
             default: NT_LAUNCH8(-1, 4); break;
         }
     } else if (d->out_dtype == ECGVIT_BF16) {

@@ -184,13 +184,31 @@ class VitEngine:
         check(l.ecgvit_fp8_quantize(ptr(x), ptr(q), None, 1, count, fmt, ptr(sc), ptr(am), st), 'fp8_quantize')
         return q, sc
 
-    def _linear(self, site, A, name, C, M, N, K, **kw):
-        """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow"""
+    def _emit8(self, kw, site, ld):
+        """ask an 8-bit product's epilogue to also write the 8-bit copy of its output that the next product (site `site`) consumes --
+        possible once that site has a scale (from the second pass on); returns True when armed"""
+        if site not in self._f8_seen:
+            return False
+        kw['epilogue'] = kw.get('epilogue', 0) | hip.EPI_QUANT_OUT
+        kw.update(q8_out=self.act['q8b'], ldq8=ld, q8_scale=self.f8_scale[site:site + 1], q8_amax=self.f8_amax[site:site + 1],
+                  q8_format=hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2)
+        return True
+
+    def _linear(self, site, A, name, C, M, N, K, emit_site=None, prequant=False, **kw):
+        """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow.
+        emit_site: the site that consumes C next (its 8-bit copy is then written by this epilogue); prequant: A's copy is already in q8b.
+        Returns True when the 8-bit copy of C was emitted."""
         if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
-            return hip.gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
-        q, sc = self._quant(site, A, M * K)
+            hip.gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
+            return False
+        if prequant:
+            q, sc = self.act['q8b'][:M * K], self.f8_scale[site:site + 1]
+        else:
+            q, sc = self._quant(site, A, M * K)
+        emitted = emit_site is not None and self._emit8(kw, emit_site, N)
         mi = self.w8_index[name]
         hip.gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
+        return emitted
 
     def transposed_weight_names(self):
         """Linear weights of the transformer blocks whose dgrad is large enough for the 256^2 forward kernel (K % 64 == 0, N >= 256)"""
@@ -214,13 +232,19 @@ class VitEngine:
             return None, 0, 0
         return torch.tensor(rows_, dtype=torch.int64, device=device), len(rows_), t
 
-    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, **kw):
-        """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one"""
+    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, prequant=False, **kw):
+        """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one.
+        Returns True when the 8-bit copy of dX was emitted for `emit_site` (fp8_linear)."""
         if self.fp8 and site is not None and M >= 2048 and name in self.w8_index:
-            q, sc = self._quant(site, dY, M * nout)
+            if prequant:
+                q, sc = self.act['q8b'][:M * nout], self.f8_scale[site:site + 1]
+            else:
+                q, sc = self._quant(site, dY, M * nout)
+            emitted = emit_site is not None and self._emit8(kw, emit_site, kin)
             mi = self.w8_index[name]
-            return hip.gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
-                            scale_b=self.w8_scale[mi:mi + 1], **kw)
+            hip.gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
+                     scale_b=self.w8_scale[mi:mi + 1], **kw)
+            return emitted
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
             hip.gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
@@ -269,6 +293,7 @@ class VitEngine:
         a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
         if self.fp8:
             a['q8'] = torch.empty(M * max(f, 3 * d), device=dev, dtype=torch.uint8)   # one quantised operand at a time
+            a['q8b'] = torch.empty(M * f, device=dev, dtype=torch.uint8)               # 8-bit copies written by a producing epilogue
         self.act, self.B = a, B
 
     # ---------------------------------------------------------------- small launch helpers
@@ -342,10 +367,10 @@ class VitEngine:
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
-            self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, epilogue=epi,
-                     bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
+            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, emit_site=8 * i + 3, epilogue=epi,
+                              bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, epilogue=epi,
+            self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, prequant=hq, epilogue=epi,
                      bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
             X = L['x2']
         return X
@@ -548,10 +573,10 @@ class VitEngine:
                 epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
-            self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, epilogue=epi, aux=L['hpre'], ldaux=f,
-                        dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
+            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, epilogue=epi, aux=L['hpre'],
+                             ldaux=f, dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
-            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5)
+            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5, prequant=bool(dq))
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
             self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
                                G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2)

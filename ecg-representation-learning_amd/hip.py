@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('ECGVIT_HIP_LIB') or os.path.join(_PKG_DIR, 'libecgvit
 F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_GRAD_AUX, EPI_MUL_AUX = 128, 256
+EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT = 128, 256, 512
 
 # default of `ecgvit_gemm_desc.tiles_per_workgroup` for every GEMM issued through `gemm()`: 0 = persistent static shares (the launch
 # owns the GPU); HipTrainStep sets it to 2 while gradient all-reduce buckets overlap the backward pass (RCCL kernels hold CUs)
@@ -40,6 +40,7 @@ class GemmDesc(Structure):
         ('bias', c_void_p), ('residual', c_void_p), ('ldr', c_int64), ('aux', c_void_p), ('ldaux', c_int64),
         ('alpha', c_float), ('dropout_p', c_float), ('dropout_seed', c_uint64),
         ('workspace', c_void_p), ('workspace_bytes', c_int64), ('colsum_out', c_void_p), ('tiles_per_workgroup', c_int32),
+        ('q8_out', c_void_p), ('ldq8', c_int64), ('q8_scale', c_void_p), ('q8_amax', c_void_p), ('q8_format', c_int32),
         ('scale_a', c_void_p), ('scale_b', c_void_p),
     ]
 
@@ -143,12 +144,14 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
               alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None, fp8_format=None, scale_a=None, scale_b=None):
+              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None, fp8_format=None, scale_a=None, scale_b=None, q8_out=None, ldq8=0, q8_scale=None,
+              q8_amax=None, q8_format=0):
     """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
     d = GemmDesc()
     d.layout, d.dtype, d.out_dtype, d.epilogue = layout, (fp8_format if fp8_format is not None else code(A.dtype)), code(C.dtype), epilogue
     d.scale_a, d.scale_b = ptr(scale_a), ptr(scale_b)   # device scalars of 8-bit operands (A, B are uint8 tensors then)
+    d.q8_out, d.ldq8, d.q8_scale, d.q8_amax, d.q8_format = ptr(q8_out), ldq8, ptr(q8_scale), ptr(q8_amax), q8_format
     d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, batch[0], batch[1]
     d.A, d.lda, d.strideA1, d.strideA2 = A.data_ptr() + a_off * A.element_size(), lda, strideA[0], strideA[1]
     d.B, d.ldb, d.strideB1, d.strideB2 = B.data_ptr() + b_off * B.element_size(), ldb, strideB[0], strideB[1]

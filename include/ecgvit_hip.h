@@ -63,6 +63,9 @@ int ecgvit_abi_version(void);
                                    instead of v -- everything the backward of `dropout(gelu(.))` needs, so that the input-gradient GEMM
                                    of the next Linear finishes with EPI_MUL_AUX alone (no erf, no mask hash in the backward)    */
 #define ECGVIT_EPI_MUL_AUX 256  /* v *= aux[m,n]                                                                              */
+#define ECGVIT_EPI_QUANT_OUT 512 /* additionally q8_out[m,n] = saturate(C[m,n] as stored / *q8_scale) in q8_format (ECGVIT_FP8_E4M3 | ECGVIT_BF8_E5M2),
+                                   *q8_amax = max(*q8_amax, max |C| as stored): the 8-bit copy the next Linear's product consumes, written
+                                   by the producer instead of by a separate quantise pass (8-bit A.B^T launches only)                        */
 #define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
                                    the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
                                    max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */
@@ -93,6 +96,7 @@ typedef struct ecgvit_gemm_desc {
                              collectives overlapped with the backward pass) hold CUs, where a static share would leave the
                              workgroups that start late a full share behind (large weight-gradient products then cut three times as many K-slices).
                              A.B^T results are identical either way; the weight-gradient sum order follows the slice count. */
+    void *q8_out; int64_t ldq8; const float *q8_scale; float *q8_amax; int32_t q8_format; /* with ECGVIT_EPI_QUANT_OUT */
     const float *scale_a, *scale_b; /* optional device scalars multiplied into alpha: the per-tensor scales of 8-bit operands
                              (x ~= q * scale), read by the kernel -- no host round trip between the quantise pass and the product */
 } ecgvit_gemm_desc;
