@@ -349,11 +349,17 @@ template <int E> struct LaneRow {
     }
 };
 
-template <int E>
+// Q8: additionally y8 = saturate(y as stored / *q8_scale) in e4m3 (the operand copy of the next Linear's fp8 product, written here
+// instead of by a quantise pass over y) and *q8_amax = max(*q8_amax, max |y|) for the next step's scale
+template <int E, bool Q8 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__restrict__ x, const float *__restrict__ gamma,
                                                                 const float *__restrict__ beta, bf16_t *__restrict__ y,
-                                                                float *__restrict__ mean, float *__restrict__ rstd, int64_t rows, float eps) {
+                                                                float *__restrict__ mean, float *__restrict__ rstd, int64_t rows, float eps,
+                                                                uint8_t *__restrict__ y8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                                float *__restrict__ q8_amax = nullptr) {
     using L = LaneRow<E>;
+    [[maybe_unused]] float q8_inv = 0.f, qmax = 0.f;
+    if constexpr (Q8) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
     constexpr int d = 64 * E;
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = blockIdx.x * 4ll + (threadIdx.x >> 6), nw = gridDim.x * 4ll;
@@ -374,7 +380,35 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__
 #pragma unroll
         for (int k = 0; k < E; ++k) v[k] = v[k] * rs * gm[k] + bt[k];
         L::store(y + r * d, lane, v);
+        if constexpr (Q8) {
+            uint8_t *row8 = y8 + r * d;
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                v[k] = (float)(bf16_t)v[k];                 // the value as stored
+                qmax = fmaxf(qmax, fabsf(v[k]));
+                v[k] = __builtin_amdgcn_fmed3f(v[k] * q8_inv, -448.f, 448.f);
+            }
+#pragma unroll
+            for (int i = 0; i < L::N16; ++i) {
+                int w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * i], v[8 * i + 1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * i + 2], v[8 * i + 3], w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * i + 4], v[8 * i + 5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * i + 6], v[8 * i + 7], w1, true);
+                u32x2 o;
+                o[0] = (uint32_t)w0; o[1] = (uint32_t)w1;
+                *reinterpret_cast<u32x2 *>(row8 + (i * 64 + lane) * 8) = o;
+            }
+            if constexpr (L::N8 == 1) {
+                int w0 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * L::N16], v[8 * L::N16 + 1], w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[8 * L::N16 + 2], v[8 * L::N16 + 3], w0, true);
+                *reinterpret_cast<uint32_t *>(row8 + 512 * L::N16 + 4 * lane) = (uint32_t)w0;
+            }
+        }
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+    if constexpr (Q8) {
+        qmax = wave_max(qmax);
+        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
     }
 }
 
@@ -656,6 +690,18 @@ int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, v
     if (dtype == ECGVIT_F32) { if (nv <= 1) LN_FWD(float, 1); else if (nv <= 2) LN_FWD(float, 2); else if (nv <= 4) LN_FWD(float, 4); else LN_FWD(float, 8); }
     else { if (nv <= 1) LN_FWD(bf16_t, 1); else if (nv <= 2) LN_FWD(bf16_t, 2); else LN_FWD(bf16_t, 4); }
 #undef LN_FWD
+    ECGVIT_CHECK_LAUNCH();
+    return ECGVIT_OK;
+}
+
+// bf16 LayerNorm forward that also writes the e4m3 copy of its output (d = 64 * {4, 8, 12, 16, 24, 32} only)
+int ecgvit_layernorm_fwd_q8(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, int64_t rows, int d,
+                            float eps, void *y8, const float *q8_scale, float *q8_amax, void *stream) {
+    if (rows <= 0 || !ln_fit(d) || !y8 || !q8_scale || !q8_amax) return ECGVIT_EINVAL;
+    const int grid = grid_for_rows(rows);
+#define LN_FIT8(EE) case EE: hipLaunchKernelGGL((layernorm_fwd_fit_kernel<EE, true>), dim3(grid), dim3(256), 0, as_stream(stream), (const bf16_t *)x, gamma, beta, (bf16_t *)y, mean, rstd, rows, eps, (uint8_t *)y8, q8_scale, q8_amax); break;
+    switch (d / 64) { LN_FIT8(4) LN_FIT8(8) LN_FIT8(12) LN_FIT8(16) LN_FIT8(24) LN_FIT8(32) default: return ECGVIT_EINVAL; }
+#undef LN_FIT8
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

@@ -201,8 +201,8 @@ class VitEngine:
         if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
             hip.gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
             return False
-        if prequant:
-            q, sc = self.act['q8b'][:M * K], self.f8_scale[site:site + 1]
+        if prequant:   # the producer already wrote A's 8-bit copy: 'q8' (LayerNorm) or q8b (a GEMM epilogue)
+            q, sc = self.act['q8' if prequant == 'q8' else 'q8b'][:M * K], self.f8_scale[site:site + 1]
         else:
             q, sc = self._quant(site, A, M * K)
         emitted = emit_site is not None and self._emit8(kw, emit_site, N)
@@ -297,9 +297,19 @@ class VitEngine:
         self.act, self.B = a, B
 
     # ---------------------------------------------------------------- small launch helpers
-    def _ln_fwd(self, x, g, b, y, mean, rstd, rows):
-        check(lib().ecgvit_layernorm_fwd(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, self.d, LN_EPS,
+    def _ln_fwd(self, x, g, b, y, mean, rstd, rows, q8_site=None):
+        """LayerNorm forward; q8_site (fp8_linear): also write the e4m3 copy of y into the operand scratch for the Linear that consumes
+        it (returns True), once that site has a scale and when the exact-fit kernel covers d"""
+        d = self.d
+        if (self.fp8 and q8_site is not None and q8_site in self._f8_seen and rows >= 2048 and d % 256 == 0
+                and d // 64 in (4, 8, 12, 16, 24, 32)):
+            check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS, ptr(self.act['q8']),
+                                                ptr(self.f8_scale[q8_site:q8_site + 1]), ptr(self.f8_amax[q8_site:q8_site + 1]), stream()),
+                  'layernorm_fwd_q8')
+            return True
+        check(lib().ecgvit_layernorm_fwd(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS,
                                          hip.code(self.dtype), stream()), 'layernorm_fwd')
+        return False
 
     def _ln_bwd(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows):
         check(lib().ecgvit_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
@@ -352,8 +362,8 @@ class VitEngine:
             lp = f'{pre}transformer.layers.{i}.'
             s0 = seed + 100 * (i + 1)
             # a6/a7: PreNorm(Attention)
-            self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M)
-            self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d)
+            q1 = self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M, q8_site=8 * i)
+            self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d, prequant='q8' if q1 else False)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
                                              T, st), 'attention_fwd')
@@ -363,11 +373,13 @@ class VitEngine:
             self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, epilogue=epi,
                      bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
             # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
-            self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M)
+            q2 = self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M,
+                              q8_site=8 * i + 2)
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
-            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, emit_site=8 * i + 3, epilogue=epi,
+            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, emit_site=8 * i + 3, prequant='q8' if q2 else False,
+                              epilogue=epi,
                               bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
             self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, prequant=hq, epilogue=epi,

@@ -60,6 +60,7 @@ SIGNATURES = {
     'ecgvit_embed_finish': (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _U, _I, _P]),
     'ecgvit_embed_bwd': (c_int, [_P, _P, _P, _P, _I, _I, _I, _F, _U, _I, _P]),
     'ecgvit_layernorm_fwd': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    'ecgvit_layernorm_fwd_q8': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     'ecgvit_layernorm_bwd_workspace': (c_int64, [_L, _I]),
     'ecgvit_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'ecgvit_layernorm_bwd_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _I, _P]),

@@ -145,6 +145,10 @@ int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
                          int64_t rows, int d, float eps, int dtype, void *stream);
+/* fp8 operand path: the same forward (bf16, d in 64 * {4, 8, 12, 16, 24, 32}) that also writes y8 = saturate(y / *q8_scale) in e4m3 and
+ * accumulates *q8_amax = max(*q8_amax, max |y|): the 8-bit operand of the next Linear's product, without a quantise pass over y */
+int ecgvit_layernorm_fwd_q8(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
+                            int64_t rows, int d, float eps, void *y8, const float *q8_scale, float *q8_amax, void *stream);
 /* dx = (dres ? dres : 0) + LN'(dy) ; dgamma/dbeta are OVERWRITTEN with the full reduction over rows.
  * `partial` is caller workspace of ecgvit_layernorm_bwd_workspace(rows, d) bytes. */
 int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d);
