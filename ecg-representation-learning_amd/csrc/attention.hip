@@ -138,11 +138,13 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
     const int d = h * 64;
     const int64_t d3 = 3 * (int64_t)d;
     const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
-    stage_image<512>(Kimg, base + d, d3, N, NK);
-    stage_image<512>(Vimg, base + 2 * d, d3, N, NK);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
+    dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
+    dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const float c = scale * 1.44269504088896340736f;
     const RowOff ro = make_row_off(lane);

@@ -640,6 +640,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     } else if (d->out_dtype == ECGVIT_BF16) {
         switch (fl) {
             case 0: NT_LAUNCH(bf16_t, 0); break;
+            case ECGVIT_EPI_BIAS: NT_LAUNCH(bf16_t, ECGVIT_EPI_BIAS); break;   // the masked objective's pixel head
             case F_LIN: NT_LAUNCH(bf16_t, F_LIN); break;
             case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH(bf16_t, F_LIN | ECGVIT_EPI_DROPOUT); break;
             case F_UP: NT_LAUNCH(bf16_t, F_UP); break;
