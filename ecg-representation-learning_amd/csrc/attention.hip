@@ -597,6 +597,9 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    // the second-dispatched half of the workgroup loses VALU arbitration to the older half in every block (priority, then age): one
+    // static priority raise for it, no per-phase flips (guide: two waves per SIMD, item 4)
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
     unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
     int item_no = 0;
     int slot = 0, par = 0, jj = 0;   // ring slot of the current slab, K / LSE buffer of the current item, running slab counter (delta / dS parity)
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t *__restric
 
 extern "C" {
 
-int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 256 blocks x 128 uint64 cycle stamps written by the persistent backward; NULL = off
+int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 768 workgroups x 128 uint64 cycle stamps written by the persistent backward; NULL = off
     return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf)) == hipSuccess ? ECGVIT_OK : ECGVIT_ELAUNCH;
 }
 

@@ -10,13 +10,13 @@ d = h * dh; bf = torch.bfloat16
 qkv = torch.randn(B * N, 3 * d, device='cuda').to(bf); out = torch.empty(B * N, d, device='cuda', dtype=bf); do = torch.randn(B * N, d, device='cuda').to(bf)
 lse = torch.empty(B * h * N, device='cuda'); dqkv = torch.empty(B * N, 3 * d, device='cuda', dtype=bf)
 check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, dh, 0.125, p, 7, hip.BF16, stream()), 'f')
-st = torch.zeros(256 * 128, dtype=torch.int64, device='cuda')
+st = torch.zeros(768 * 128, dtype=torch.int64, device='cuda')   # one 128-word record per workgroup (the backward runs up to 768)
 check(lib().ecgvit_debug_attn_stamps(ptr(st)), 'stamps')
 for _ in range(3):
     check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dqkv), B, N, h, dh, 0.125, p, 7, hip.BF16, stream()), 'b')
 torch.cuda.synchronize()
 check(lib().ecgvit_debug_attn_stamps(None), 'stamps')
-t = st.cpu().view(256, 4, 32).double().numpy()
+t = st.cpu().view(768, 4, 32).double().numpy()
 for item in range(4):
     x = t[:, item]
     start, pre, post, bar, loop_end, epi_end = x[:, 0], x[:, 1:9], x[:, 9:17], x[:, 17:25], x[:, 25], x[:, 26]

@@ -12,7 +12,7 @@ bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'tn', 'attn'])
+    kind = rng.choice(['nt', 'nt', 'nt8', 'tn', 'attn'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -24,9 +24,25 @@ while time.time() < t_end:
         want = ref if out_f32 else ref.to(bf)
         for _ in range(4):
             C.fill_(float('nan'))
-            hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N)
+            hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, tiles_per_workgroup=rng.choice([0, 0, 1, 2, 3]))
             if not torch.equal(C, want):
                 bad += 1; print('NT MISMATCH', M, N, K, out_f32, int((C != want).sum()), flush=True)
+        n_nt += 1
+    elif kind == 'nt8':      # 8-bit operands (e4m3 x e4m3 / e5m2 x e4m3), small integers: exact
+        M = rng.choice([2048, 4133, 20000, 66000, 128256]) + rng.randrange(0, 256)
+        N = rng.choice([128, 256, 520, 768, 1024, 3072, 4096])
+        K = 128 * rng.randrange(3, 33)
+        afmt, adt = rng.choice([(hip.FP8_E4M3, torch.float8_e4m3fn), (hip.BF8_E5M2, torch.float8_e5m2)])
+        A = torch.randint(-2, 3, (M, K), device='cuda').float().to(adt); B = torch.randint(-2, 3, (N, K), device='cuda').float().to(torch.float8_e4m3fn)
+        want = (A.float() @ B.float().t()).to(bf)
+        C = torch.empty(M, N, device='cuda', dtype=bf)
+        one = torch.ones(1, device='cuda')
+        for _ in range(4):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_NT, A.view(torch.uint8), B.view(torch.uint8), C, M, N, K, K, K, N, fp8_format=afmt, scale_a=one, scale_b=one,
+                     tiles_per_workgroup=rng.choice([0, 0, 2]))
+            if not torch.equal(C, want):
+                bad += 1; print('NT8 MISMATCH', M, N, K, afmt, int((C != want).sum()), flush=True)
         n_nt += 1
     elif kind == 'tn':
         M = 256 * rng.randrange(1, 13); N = 256 * rng.randrange(1, 13)
