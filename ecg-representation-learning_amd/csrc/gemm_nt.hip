@@ -70,17 +70,31 @@ __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast
 // -> accumulate -> store; same order and rounding points as gemm_bf16.hip's epilogue_value.  All global accesses are buffer
 // operations: `off` is the byte offset of (m, n) in C scaled per buffer by the caller, 0x80000000 for a masked lane -- beyond
 // every descriptor's num_records, so loads return zero and stores are dropped, and the body needs no exec-mask branch.
+// (m, ncol, ok) are the run's coordinates in the ACCUMULATOR layout -- what the arithmetic, the dropout hash, the column sums use;
+// (mm, ncm, okm) those of the run this lane moves to or from MEMORY for 16-bit buffers: the vector-memory path merges only
+// ADJACENT lanes into one request, and in the accumulator layout adjacent lanes are adjacent ROWS (64 requests of 16 B per wave
+// instruction: 27 ns per instruction and CU, loads and stores alike, `tools/ta_rate.hip`), so every 16-B run crosses the lanes
+// once (4 ds_bpermute_b32) to a layout where the four lanes of a quad hold the four runs of one 64-B half-line (7-8 ns).
 struct NtBufs {
     __amdgpu_buffer_rsrc_t c, res, aux, q8;
     int ldc2, ldr2, ldx2, ldq;   // row pitches in bytes
     float q8_inv;                // 1 / scale of the 8-bit output copy (ECGVIT_EPI_QUANT_OUT)
     int q8_bf8;                  // its format: 0 = e4m3, 1 = e5m2
+    int t_out, t_in;             // ds_bpermute byte addresses: accumulator layout -> memory layout and back (see nt_epilogue)
 };
 constexpr uint32_t NT_OOB = 0x80000000u;
 
+// the same lane permutation on the four dwords of a 16-B run (LDS crossbar, no LDS memory)
+__device__ __forceinline__ u32x4 nt_permute(const u32x4 &x, int addr) {
+    u32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)x[k]);
+    return y;
+}
+
 template <typename TO, int FL>
-__device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, const NtBufs &bf, const EpiParams &e,
-                                        const u32x4 &res, const u32x4 &auxin, float *cs8, float &qmax) {
+__device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, uint32_t mm, uint32_t ncm, bool okm,
+                                        const NtBufs &bf, const EpiParams &e, const u32x4 &res, const u32x4 &auxin, float *cs8, float &qmax) {
     if (e.alpha != 1.f) {   // wave-uniform
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
@@ -110,7 +124,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] = gelu_fast(bf16_lo(sav[k])); v[2 * k + 1] = gelu_fast(bf16_hi(sav[k])); }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(sav, bf.aux, ok ? m * (uint32_t)bf.ldx2 + ncol * 2 : NT_OOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
         }
         if (drop) {
 #pragma unroll
@@ -128,16 +142,16 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_lo(res[k]); v[2 * k + 1] += bf16_hi(res[k]); }
         }
-        const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 2 : NT_OOB;
+        const uint32_t off = okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB;
         if (NT_HAS(ECGVIT_EPI_ACCUM)) {
-            const u32x4 old = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 0, 0);
+            const u32x4 old = nt_permute(__builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 0, 0), bf.t_in);
 #pragma unroll
             for (int k = 0; k < 4; ++k) { v[2 * k] += bf16_lo(old[k]); v[2 * k + 1] += bf16_hi(old[k]); }
         }
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(out, bf.c, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, 0);
         if (NT_HAS(ECGVIT_EPI_COLSUM)) {   // of the values as stored; masked lanes add nothing
 #pragma unroll
             for (int k = 0; k < 4; ++k) { cs8[2 * k] += ok ? bf16_lo(out[k]) : 0.f; cs8[2 * k + 1] += ok ? bf16_hi(out[k]) : 0.f; }
@@ -162,10 +176,10 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
                 w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
             }
             u32x2 q;
-            q[0] = (uint32_t)w0; q[1] = (uint32_t)w1;
-            __builtin_amdgcn_raw_buffer_store_b64(q, bf.q8, ok ? m * (uint32_t)bf.ldq + ncol : NT_OOB, 0, 0);
+            q[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w0); q[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w1);
+            __builtin_amdgcn_raw_buffer_store_b64(q, bf.q8, okm ? mm * (uint32_t)bf.ldq + ncm : NT_OOB, 0, 0);
         }
-    } else {
+    } else {   // f32 outputs: 32 B per lane stay in the accumulator layout (no train-step launch takes this branch)
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
         if (NT_HAS(ECGVIT_EPI_ACCUM)) {
             const u32x4 o0 = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 0, 0), o1 = __builtin_amdgcn_raw_buffer_load_b128(bf.c, off, 16, 0);
@@ -206,16 +220,22 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
     for (int k = 0; k < 16; ++k) cs[k] = 0.f;
     float qmax = 0.f;
     const uint32_t mrow = (uint32_t)(m0 + wm * 128 + c);
+    // memory layout of a 16-row x 32-column half block: lane t moves row t>>2, run t&3 (accumulator layout: row s&15, run s>>4)
+    const uint32_t mrowm = (uint32_t)(m0 + wm * 128 + (lane >> 2));
+    const int nbm = n0 + wn * 64 + 8 * (lane & 3);
+    const bool nokm0 = nbm < N, nokm1 = nbm + 32 < N;
     constexpr bool kBf = sizeof(TO) == 2;
     constexpr bool kLight = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
     const bool want_res = kBf && NT_HAS(ECGVIT_EPI_RESIDUAL), want_aux = kBf && NT_HAS(ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_GELU_BWD);
     // rows >= M fall beyond num_records by themselves; masked columns are forced there
     auto ld_res = [&](int i, int h) {
-        return want_res ? __builtin_amdgcn_raw_buffer_load_b128(bf.res, (h ? nok1 : nok0) ? (mrow + 16 * i) * (uint32_t)bf.ldr2 + (nb + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+        return want_res ? __builtin_amdgcn_raw_buffer_load_b128(bf.res, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldr2 + (nbm + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
     };
     auto ld_aux = [&](int i, int h) {
-        return want_aux ? __builtin_amdgcn_raw_buffer_load_b128(bf.aux, (h ? nok1 : nok0) ? (mrow + 16 * i) * (uint32_t)bf.ldx2 + (nb + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+        return want_aux ? __builtin_amdgcn_raw_buffer_load_b128(bf.aux, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldx2 + (nbm + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
     };
+    // loaded runs arrive in the memory layout; to the accumulator layout when they are consumed
+    auto to_acc = [&](const u32x4 &x, bool want) { return want ? nt_permute(x, bf.t_in) : x; };
     if constexpr (kLight) {
         // light bodies: every row load of the tile is issued up front (the 64 fragment registers are free now), then the 8 row steps
         // run fully unrolled on the accumulators in place; stores are fire-and-forget
@@ -229,10 +249,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             float v0[8], v1[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
-            const uint32_t m = mrow + 16 * i;
-            const bool mok = (int)m < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, R[i][0], X[i][0], cs, qmax);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, R[i][1], X[i][1], cs + 8, qmax);
+            const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
+            const bool mok = (int)m < M, mokm = (int)mm < M;
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc(X[i][0], want_aux), cs, qmax);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(R[i][1], want_res), to_acc(X[i][1], want_aux),
+                            cs + 8, qmax);
         }
     } else {
         // heavy bodies must exist ONCE in the instruction stream (I-cache): rolled loop, only the accumulator pick is a switch;
@@ -251,10 +272,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         break;
             switch (i) { NT_PICK(0) NT_PICK(1) NT_PICK(2) NT_PICK(3) NT_PICK(4) NT_PICK(5) NT_PICK(6) default: NT_PICK(7) }
 #undef NT_PICK
-            const uint32_t m = mrow + 16 * i;
-            const bool mok = (int)m < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, bf, e, r0, a0, cs, qmax);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, bf, e, r1, a1, cs + 8, qmax);
+            const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
+            const bool mok = (int)m < M, mokm = (int)mm < M;
+            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc(a0, want_aux), cs, qmax);
+            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc(a1, want_aux), cs + 8, qmax);
         }
     }
     if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // one atomic max per wave and tile (non-negative floats order as integers)
@@ -323,6 +344,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     bf.ldq = (int)d.ldq8;
     bf.q8 = __builtin_amdgcn_make_buffer_rsrc(d.q8_out, 0, d.q8_out ? (uint32_t)((int64_t)M * bf.ldq) : 0u, 0x00020000);
     bf.q8_bf8 = d.q8_format == ECGVIT_BF8_E5M2;
+    bf.t_out = ((lane >> 2) + 16 * (lane & 3)) << 2;   // memory-layout lane t takes its run from accumulator-layout lane (t>>2) + 16 (t&3)
+    bf.t_in = (4 * (lane & 15) + (lane >> 4)) << 2;    // and back
     bf.q8_inv = 0.f;
     if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) { const float qs = *d.q8_scale; bf.q8_inv = qs > 0.f ? 1.0f / qs : 0.f; }
     // this wave's two DMA pieces of a half-tile: rows 16*wave + {0..7}, {8..15}; LDS chunk p of row r holds source chunk p ^ f(r)
