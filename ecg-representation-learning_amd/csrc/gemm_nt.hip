@@ -2,16 +2,19 @@
 // shadows, the input-gradient products): M x N x K with both operands K-contiguous, K % 64 == 0, N % 8 == 0.
 //
 // gemm_nt_kernel ("R"): persistent, 256 x 256 x 64 block tile, 8 waves (2 x 4, wave tile 128 x 64), v_mfma_f32_16x16x32_bf16.
-//   * main loop: four 256-cycle phases per K-tile (one 64 x 32 output quadrant each: 12 / 4 / 8 / 0 ds_read_b128, nothing read
-//     twice); operands arrive as 16-KiB half-tiles by LDS-DMA (`buffer_load ... lds`) from a stream that runs CONTINUOUSLY across
-//     output tiles -- activations two K-tiles ahead in a 3-slot ring per half, weights one K-tile ahead in 2 slots (10 x 16 KiB = all
-//     of LDS), one counted vmcnt(4) per K-tile, never a drain; waves 4-7 run one barrier behind waves 0-3 (ping-pong per SIMD).
+//   * main loop: four quadrants per K-tile (one 64 x 32 output quadrant each: 12 / 4 / 8 / 0 ds_read_b128, nothing read twice);
+//     operands arrive as 16-KiB half-tiles by LDS-DMA (`buffer_load ... lds`) from a stream that runs CONTINUOUSLY across output
+//     tiles -- activations two K-tiles ahead in a 3-slot ring per half, weights one K-tile ahead in 2 slots (10 x 16 KiB = all of
+//     LDS), one counted vmcnt(4) and ONE workgroup barrier per K-tile, never a drain; waves 4-7 pass that barrier one quadrant
+//     later in their program than waves 0-3 (before their register-only quadrant 4), so each SIMD's two waves alternate between
+//     reading fragments and multiplying without any barrier inside the K-tile.
 //   * the MFMA takes the WEIGHT fragment as its first operand and the activation fragment as its second, so an accumulator
 //     register quad holds 4 consecutive output COLUMNS of one row (D row = 4*(lane>>4) + reg <-> n, D col = lane&15 <-> m).  The
 //     weight fragment of n-tile j reads image rows 32*(j>>1) + 8*(i>>2) + 4*(j&1) + (i&3) (i = lane&15), which makes the 16
 //     values a lane holds for one output row two runs of 8 consecutive columns (8q .. 8q+7 and 32+8q .. 32+8q+7, q = lane>>4):
 //     the epilogue runs straight out of the accumulators -- bias / GELU / dropout / residual / x-aux / column sums in f32, two
-//     16-B stores per lane and row (64 contiguous bytes per row and instruction) -- with no LDS round trip and no patch buffer.
+//     16-B runs per lane and row, each moved across the lanes once (ds_bpermute) so that a quad stores a 64-B half-line -- with
+//     no LDS round trip and no patch buffer.
 //     The kernel it replaces (gemm_bf16_q_kernel) drained through per-wave LDS patches: 256 KiB of ds_write_b32 per tile at
 //     64 B/clk plus the read-back, inside a 10.4k-cycle drain per tile (20 % of a K = 768 tile).
 //   * LDS images (the DMA destination is wave-uniform base + lane*16, so swizzles go on the per-lane SOURCE address):
@@ -409,10 +412,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             }                                                                                                                    \
         }                                                                                                                        \
     } while (0)
+    // a quadrant = its fragment reads (and up to two DMA pieces), one LDS wait, 16 MFMAs at raised priority; NO workgroup barrier
 #define R_PHASE_SYNC_A()                                   \
     do {                                                   \
         __builtin_amdgcn_sched_barrier(0);                 \
-        __builtin_amdgcn_s_barrier();                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                 \
         __builtin_amdgcn_s_setprio(1);                     \
@@ -420,8 +423,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #define R_PHASE_SYNC_B()                   \
     do {                                   \
         __builtin_amdgcn_s_setprio(0);     \
-        __builtin_amdgcn_sched_barrier(0); \
-        __builtin_amdgcn_s_barrier();      \
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
@@ -451,13 +452,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         }                                                  \
     } while (0)
 
-    // ---- prologue: A(0), B(0), A(1)
+    // ---- prologue: A(0), B(0), A(1); the trailing group also the first half of B(1), which it otherwise issues in quadrant 4 of the
+    // K-tile before (see the loop)
     R_DMA_A(0, 0, a_base); R_DMA_A(1, 0, a_base); R_ADV_A();
     R_DMA_B(0, 0, b_base); R_DMA_B(1, 0, b_base); R_ADV_B();
     R_DMA_A(0, 1, a_base + a_kt * (BK * 2)); R_DMA_A(1, 1, a_base + a_kt * (BK * 2)); R_ADV_A();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (late) {
+        R_DMA_B(0, 1, b_base + b_kt * (BK * 2));
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    if (late) __builtin_amdgcn_s_barrier();
 
     int ga = 0, gb = 0;   // ring slots of the K-tile being multiplied
     bool pre = false;     // the coming K-tile's DMA pieces were issued ahead of the previous tile's epilogue
@@ -484,8 +490,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             bf16x8 a[4][2], b0[2][2], b1[2][2];
             const bool pre_k = pre;
             pre = false;
-            const bool b_issue = b_ok && !pre_k;
-            // ---------------- phase 1: rows 0-63 x n-tiles 0,1
+            const bool a_iss = a_ok && !pre_k;      // A(kt+2) goes out during this K-tile (both halves or neither: a_ok changes after the second)
+            // ONE workgroup barrier per K-tile (R_BAR): the leading group (waves 0-3) passes it after quadrant 4, the trailing group
+            // (waves 4-7, same SIMDs) before its quadrant 4 -- one quadrant behind, so that on every SIMD one wave multiplies while
+            // the other reads fragments.  Behind the barrier K-tile kt+1 is visible to everyone (each wave waited for its own pieces:
+            // everything but the four of A(kt+2)) and nobody reads K-tile kt from LDS any more (quadrant 4 runs from registers), so
+            // the pieces issued after it -- B(kt+2) into B(kt)'s slot, A(kt+3) into A(kt)'s -- are safe.  Each wave issues them two per
+            // quadrant in the order B half 0, B half 1, A half 0, A half 1 counted from ITS barrier: the leading group in quadrants
+            // 1-4 of the next K-tile, the trailing group in quadrant 4 of this one and 1-3 of the next.
+#define R_BAR()                                                                  \
+    do {                                                                         \
+        if (a_iss) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+        else if (pre_k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        __builtin_amdgcn_s_barrier();                                            \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+    } while (0)
+            // ---------------- quadrant 1: rows 0-63 x n-tiles 0,1
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -495,58 +517,65 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
-            if (b_issue) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+            if (!pre_k && b_ok) {
+                if (!late) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+                else { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
+            }
             R_PHASE_SYNC_A();
             R_QUAD(0, 0, b0);
             R_PHASE_SYNC_B();
-            // ---------------- phase 2: rows 0-63 x n-tiles 2,3
+            // ---------------- quadrant 2: rows 0-63 x n-tiles 2,3
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (s * 64)));
-            if (b_issue) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
+            if (!late) {
+                if (!pre_k && b_ok) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
+            } else if (a_iss) {
+                R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+            }
             R_PHASE_SYNC_A();
             R_QUAD(0, 2, b1);
             R_PHASE_SYNC_B();
-            // ---------------- phase 3: rows 64-127 x n-tiles 2,3
+            // ---------------- quadrant 3: rows 64-127 x n-tiles 2,3
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (s * 64)));
-            const bool a_issue = a_ok && !pre_k;
-            if (a_issue) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+            if (a_iss) {
+                if (!late) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+                else { R_DMA_A(1, ga2, a_base + a_kt * (BK * 2)); R_ADV_A(); }
+            }
             R_PHASE_SYNC_A();
             R_QUAD(4, 2, b1);
             R_PHASE_SYNC_B();
-            // ---------------- phase 4: rows 64-127 x n-tiles 0,1 (no LDS reads); the K-tile's one counted wait: all but A(kt+2) landed
-            if (a_issue) {
+            // ---------------- quadrant 4: rows 64-127 x n-tiles 0,1 (no LDS reads)
+            if (late) {
+                R_BAR();
+                if (b_ok) R_DMA_B(0, gb, b_base + b_kt * (BK * 2));   // first half of B(kt+2), into the slot of B(kt)
+            } else if (a_iss) {
                 R_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
                 R_ADV_A();
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else if (pre_k) {
-                // first K-tile after an epilogue: B(1) and A(2) went out BEFORE the epilogue's stores, so B(1) (needed next) is older
-                // than A(2) + the NST stores -- the stores stay in flight across this K-tile instead of being waited for here
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            R_PHASE_SYNC_A();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
             R_QUAD(4, 0, b0);
             R_PHASE_SYNC_B();
+            if (!late) R_BAR();
             ga = ga == 2 ? 0 : ga + 1;
             gb ^= 1;
         }
-        // ---------------- output tile done: both wave groups drain together, straight from the accumulators (no LDS involved, so
-        // the operand stream of the next tile -- A two K-tiles, B one K-tile ahead -- stays in flight underneath)
+#undef R_BAR
+        // ---------------- output tile done; the epilogue runs straight from the accumulators (no LDS memory involved, so the operand
+        // stream of the next tile stays in flight underneath and no barrier surrounds it).
         const int next_it = it + (int)gridDim.x;
         const bool has_next = next_it < nitems;
-        if (!late) __builtin_amdgcn_s_barrier();     // leading group: wait for the trailing group's last MFMA phase
-        // Every fragment read of the last K-tile is done (reads precede their phase's MFMAs): its ring slots are free.  Issue what
-        // the next tile's K-tile 0 would issue -- B(1), A(2) -- NOW, ahead of the epilogue's stores.  vmcnt retires in issue order, and
-        // a CU takes ~10k cycles to push a 128-KiB tile out (12.6 B/clk: DESIGN.md 4), so a counted wait that sits BEHIND the stores
-        // stalls the next main loop until they are acknowledged; this way the first wait that covers them comes two K-tiles later.
+        // Issue what the next tile's K-tile 0 would issue -- B(1), A(2) -- NOW, ahead of the epilogue's stores: vmcnt retires in
+        // issue order, so a counted wait that sits BEHIND the stores stalls the next main loop until they are acknowledged; this
+        // way the first wait that covers them comes two K-tiles later.  (The trailing group has sent B(1)'s first half already.)
         if (a_ok && b_ok && has_next) {
-            R_DMA_B(0, gb ^ 1, b_base + b_kt * (BK * 2)); R_DMA_B(1, gb ^ 1, b_base + b_kt * (BK * 2)); R_ADV_B();
+            if (!late) R_DMA_B(0, gb ^ 1, b_base + b_kt * (BK * 2));
+            R_DMA_B(1, gb ^ 1, b_base + b_kt * (BK * 2)); R_ADV_B();
             const int gaf = ga == 0 ? 2 : ga - 1;
             R_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); R_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); R_ADV_A();
             pre = true;
@@ -554,7 +583,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
         nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane);
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
-        if (late && has_next) __builtin_amdgcn_s_barrier();   // trailing group falls one barrier behind again
         if (!has_next) break;
         it = next_it;
         if (a_it == it) { cm0 = nm0; cn0 = nn0; }                     // the producer cursor already decoded this item
