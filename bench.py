@@ -206,6 +206,10 @@ def main():
     ap.add_argument('--no-probe', action='store_true')
     ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
     ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
+    ap.add_argument('--single-rank-collectives', action='store_true',
+                    help='diagnostic, --gpus 1 only: a 1-rank RCCL group with the N > 1 code path switched on (start broadcast, per-bucket '
+                         'all-reduces overlapped with backward, chunked GEMM launches): what the data-parallel machinery costs without a wire')
+    ap.add_argument('--grad-comm', choices=['f32', 'bf16'], default='f32', help='dtype of the gradient buckets on the wire (N > 1)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -214,9 +218,10 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.single_rank_collectives:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import ecg_representation_learning_amd as E
@@ -246,7 +251,8 @@ def main():
             y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank)).to(dev)   # (B, m) int32
         n_total = steps + warmup
         step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total),
-                              sync_nonfinite=not args.defer_nonfinite)
+                              sync_nonfinite=not args.defer_nonfinite, single_rank_collectives=args.single_rank_collectives,
+                              grad_comm_dtype=torch.bfloat16 if args.grad_comm == 'bf16' else torch.float32)
         run_step = step.step_masked if objective == 'masked' else step.step
         probe = None
         if not args.no_probe and dtype == torch.bfloat16:
@@ -319,7 +325,7 @@ def main():
                             f'{"+RCCL all-reduce" if world > 1 else ""}), dropout {conf.hidden_dropout_prob}, '
                             f'{batch} records/GPU x 12 leads x {conf.max_signal_length} samples, patch {conf.patch_size} '
                             f'({conf.max_signal_length // conf.patch_size + (0 if args.objective == "masked" else 1)} tokens), random-init weights, inputs resident in HBM'),
-                'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}',
+                'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}' + ('+single-rank-collectives' if args.single_rank_collectives else ''),
                 'hidden': conf.hidden_size, 'layers': conf.num_hidden_layers, 'heads': conf.num_attention_heads,
             },
             'final_loss': final_loss,
@@ -333,7 +339,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(conf, masked=args.objective == 'masked')
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.single_rank_collectives:
         import torch.distributed as dist
         dist.destroy_process_group()
 

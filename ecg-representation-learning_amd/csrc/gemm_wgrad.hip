@@ -398,9 +398,10 @@ inline int choose_splits2(const ecgvit_gemm_desc *d, int ntile) {
     // 27 tiles x 8 slices = 216 blocks wastes 16 % of the chip for the whole launch, 27 x 9 = 243 (XCD-contiguous order) does not
     if (s >= 8 && (s & ~7) * ntile * 100 >= s * ntile * 93) s &= ~7;
     if (s < 1) s = 1;
-    // the launch shares the GPU (tiles_per_workgroup > 0: RCCL kernels hold CUs): a one-round grid would leave the blocks that find no
-    // free CU a whole round behind -- three times as many, shorter slices are handed out as CUs free up (XCD-contiguous order)
-    if (d->tiles_per_workgroup > 0) s *= 3;
+    // tiles_per_workgroup (launches that share the GPU with RCCL kernels) does NOT change the slicing here.  Three times as many,
+    // shorter slices would bound the tail of a block that finds its CU held, but they cost every launch: measured inside the step on
+    // a 1-rank RCCL group (bench.py --single-rank-collectives, profiles/r02_dp_single_rank.txt) +2.3 ms of gemm_wgrad and +1.1 ms of
+    // split-K reduce per step, against the ~8 % of the backward during which a bucket's all-reduce actually holds CUs.
     s = std::min(s, std::max(1, ksteps / 16));   // keep >= 16 K-steps per slice
     return std::max(1, std::min(s, 64));
 }

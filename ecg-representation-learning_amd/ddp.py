@@ -26,14 +26,14 @@ def rank_seed(base_seed: int, rank: int) -> int:
     return base_seed + rank
 
 
-def allreduce_flat_(gflat: torch.Tensor, group=None, bucket_elems: int = 0):
+def allreduce_flat_(gflat: torch.Tensor, group=None, bucket_elems: int = 0, single_rank: bool = False):
     """In-place SUM all-reduce of the flat gradient buffer. bucket_elems > 0 splits it into contiguous buckets
     (issued back to back on the collective stream; one bucket = one collective). Returns the world size, i.e. the
     factor the caller divides by (folded into the optimiser kernel as grad_scale = 1 / world)."""
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not single_rank:
         return 1
     if bucket_elems <= 0 or bucket_elems >= gflat.numel():
         dist.all_reduce(gflat, op=dist.ReduceOp.SUM, group=group)
@@ -46,9 +46,9 @@ def allreduce_flat_(gflat: torch.Tensor, group=None, bucket_elems: int = 0):
     return world
 
 
-def broadcast_flat_(pflat: torch.Tensor, src: int = 0, group=None):
+def broadcast_flat_(pflat: torch.Tensor, src: int = 0, group=None, single_rank: bool = False):
     """make every rank start from rank `src`'s weights (one collective over the flat parameter buffer)"""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or single_rank):
         dist.broadcast(pflat, src=src, group=group)
 
 
@@ -63,11 +63,14 @@ class GradExchange:
     relative error of the reduced gradient ~2^-8 * sqrt(world); the optimiser state and the weights stay f32).
     The caller folds 1/world into its update."""
 
-    def __init__(self, ranges, group=None, overlap=True, comm_dtype=torch.float32):
+    def __init__(self, ranges, group=None, overlap=True, comm_dtype=torch.float32, single_rank_collectives=False):
+        """single_rank_collectives: issue the collectives on a 1-rank group too (they are skipped otherwise) -- the whole RCCL
+        code path, its streams and staging buffers included, then runs on one GPU (tests/test_gpu_ddp.py)"""
         if comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError('comm_dtype must be torch.float32 or torch.bfloat16')
         self.ranges, self.group, self.overlap, self.comm_dtype = dict(ranges), group, overlap, comm_dtype
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.active = self.world > 1 or (single_rank_collectives and dist.is_available() and dist.is_initialized())
         self._buf = None
         self._works, self._launched, self._g = [], set(), None
 
@@ -81,7 +84,7 @@ class GradExchange:
         return self._buf
 
     def bucket_ready(self, tag):
-        if self.world == 1 or not self.overlap or tag not in self.ranges or tag in self._launched:
+        if not self.active or not self.overlap or tag not in self.ranges or tag in self._launched:
             return
         lo, hi = self.ranges[tag]
         self._launched.add(tag)
@@ -94,7 +97,7 @@ class GradExchange:
 
     def finish(self):
         """after the backward pass: every element of the gradient buffer holds the SUM over ranks when this returns"""
-        if self.world == 1:
+        if not self.active:
             return
         g = self._g
         if self.overlap:
@@ -109,7 +112,7 @@ class GradExchange:
         elif self.comm_dtype != torch.float32:
             buf = self._stage(g)
             buf.copy_(g)
-            allreduce_flat_(buf, group=self.group)
+            allreduce_flat_(buf, group=self.group, single_rank=True)
             g.copy_(buf)
         else:
-            allreduce_flat_(g, group=self.group)
+            allreduce_flat_(g, group=self.group, single_rank=True)

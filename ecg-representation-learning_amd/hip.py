@@ -175,5 +175,4 @@ def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw):
 def gemm_workspace_bytes(layout, dtype, M, N, K):
     d = GemmDesc()
     d.layout, d.dtype, d.out_dtype, d.M, d.N, d.K, d.batch1, d.batch2 = layout, code(dtype), F32, M, N, K, 1, 1
-    d.tiles_per_workgroup = 1   # size for the shared-GPU slicing too (three times the slices of a launch that owns the GPU)
     return lib().ecgvit_gemm_workspace(byref(d))

@@ -81,9 +81,11 @@ class HipTrainStep:
     """
 
     def __init__(self, model, args=None, max_grad_norm=1.0, sync_nonfinite=True, process_group=None, overlap_allreduce=True,
-                 grad_comm_dtype=torch.float32):
+                 grad_comm_dtype=torch.float32, single_rank_collectives=False):
         """grad_comm_dtype: torch.float32 (exact exchange) or torch.bfloat16 (each bucket is cast to bf16, all-reduced at half the
-        bytes over xGMI and added back into the f32 gradient buffer; the optimiser still sees f32)"""
+        bytes over xGMI and added back into the f32 gradient buffer; the optimiser still sees f32).
+        single_rank_collectives: run the start broadcast and the gradient exchange on a 1-rank group too (skipped otherwise), so
+        that the whole RCCL path -- collective stream, staging buffers, chunked GEMM launches -- can be exercised on one GPU"""
         self.model = model
         self.args = {**get_train_args(), **(args or dict())}
         ca(optimizer=self.args['optimizer'], schedule=self.args['schedule'])
@@ -100,6 +102,7 @@ class HipTrainStep:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        self.collectives = self.world > 1 or (bool(single_rank_collectives) and dist.is_available() and dist.is_initialized())
         self.overlap = overlap_allreduce
         if grad_comm_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError('grad_comm_dtype must be torch.float32 or torch.bfloat16')
@@ -123,9 +126,9 @@ class HipTrainStep:
             self.sumsq = torch.zeros(1, device=m._pflat.device, dtype=torch.float32)
             self.ws = torch.empty(hip.lib().ecgvit_sumsq_workspace(m._pflat.numel()), device=m._pflat.device, dtype=torch.uint8)
             self._replicas_synced = False
-        if self.world > 1 and not self._replicas_synced:
+        if self.collectives and not self._replicas_synced:
             # data-parallel replicas must start from the same weights whatever each rank's RNG produced: rank 0's flat buffer wins
-            ddp.broadcast_flat_(m._pflat, src=0, group=self.pg)
+            ddp.broadcast_flat_(m._pflat, src=0, group=self.pg, single_rank=True)
             if m._wlow is not None:
                 m.refresh_low_precision_weights(force=True)
             self._replicas_synced = True
@@ -141,10 +144,10 @@ class HipTrainStep:
     # -- gradient all-reduce (RCCL over xGMI): ddp.GradExchange over the flat gradient buffer
     def _arm_overlap(self, model):
         eng = model._engine()
-        if self.world > 1:
+        if self.collectives:
             if self._xchg is None or self._xchg_layout is not model._layout:
                 self._xchg = ddp.GradExchange(model._layout.buckets_in_ready_order(eng.Ly), group=self.pg, overlap=self.overlap,
-                                              comm_dtype=self.comm_dtype)
+                                              comm_dtype=self.comm_dtype, single_rank_collectives=True)
                 self._xchg_layout = model._layout
             self._xchg.begin(model._gflat)
             eng.on_grads_ready = self._xchg.bucket_ready if self.overlap else None
@@ -177,7 +180,7 @@ class HipTrainStep:
 
     def _update(self, model):
         gflat = model._gflat
-        if self.world > 1:
+        if self.collectives:
             self._xchg.finish()
             hip.GEMM_TILES_PER_WORKGROUP = 0
         l = hip.lib()

@@ -1,0 +1,87 @@
+"""-m gpu: the data-parallel train step's RCCL path on ONE GPU.
+
+A 1-rank `nccl` (= RCCL) process group with `single_rank_collectives=True` makes HipTrainStep issue everything the N > 1 path issues --
+the start broadcast of the flat parameter buffer, one asynchronous all-reduce per gradient bucket from inside the backward pass (on
+RCCL's stream, overlapped with the remaining backward kernels, which are launched as dispatcher-balanced chunks meanwhile), the bf16
+staging copies, the waits in front of the fused norm + clip + AdamW -- with a sum over one rank as the arithmetic.  The result must
+therefore equal the plain single-process step: bit for bit with f32 on the wire, within bf16 rounding with bf16 on the wire.
+(Multi-rank SEMANTICS -- shards, sum, 1/world -- are pinned by the world_size-2 gloo test on CPU, tests/test_ddp_gloo.py.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+import ecg_representation_learning_amd as E
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def nccl_group():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    yield None
+    dist.destroy_process_group()
+
+
+def _model(seed=5):
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    torch.manual_seed(seed)
+    return E.EcgVit(config=conf, compute_dtype=BF16).cuda().train()
+
+
+def _run(steps, **kw):
+    m = _model()
+    x, y = E.workload.synthetic_batch(24, length=5000, seed=3)
+    x, y = x.cuda(), y.cuda()
+    st = E.HipTrainStep(m, dict(n_step=20, warmup_ratio=0.0), **kw)
+    torch.manual_seed(99)               # the host RNG draws the per-step dropout seeds
+    losses = [float(st.step(x, y)[0]) for _ in range(steps)]
+    st.finish()
+    torch.cuda.synchronize()
+    return losses, m._pflat.clone(), st.grad_norm()
+
+
+def test_rccl_path_on_one_rank_equals_plain_step(nccl_group):
+    ref_l, ref_p, ref_n = _run(3)                                              # collectives skipped (1 rank)
+    # f32 on the wire: a sum over one rank is the identity, and the chunked GEMM launches of the overlapped backward hand the same
+    # tiles to other workgroups without changing any sum -- bit-identical in both modes
+    for kw in (dict(overlap_allreduce=False), dict(overlap_allreduce=True)):
+        l, p, n = _run(3, single_rank_collectives=True, **kw)
+        assert l == ref_l and torch.equal(p, ref_p) and n == ref_n, kw
+    for kw in (dict(overlap_allreduce=True), dict(overlap_allreduce=False)):
+        l, p, n = _run(3, single_rank_collectives=True, grad_comm_dtype=BF16, **kw)
+        # tolerance: the gradient passes through bf16 once (2^-9 relative per element) before AdamW; three steps at lr 3e-4
+        assert all(abs(a - b) < 2e-3 * abs(b) + 1e-4 for a, b in zip(l, ref_l)), (l, ref_l)
+        assert float((p - ref_p).norm() / ref_p.norm()) < 1e-3
+        assert abs(n - ref_n) < 1e-2 * ref_n
+
+
+def test_grad_exchange_streams_on_gpu(nccl_group):
+    """GradExchange alone on device buffers: buckets reduced on RCCL's stream while the producer stream keeps writing later buckets"""
+    n = 1 << 22
+    ranges = [(f'b{i}', (i * (n // 8), (i + 1) * (n // 8))) for i in range(8)]
+    for kw in (dict(comm_dtype=torch.float32), dict(comm_dtype=BF16)):
+        g = torch.zeros(n, device='cuda')
+        ex = E.ddp.GradExchange(ranges, overlap=True, single_rank_collectives=True, **kw)
+        ex.begin(g)
+        for i, (tag, (lo, hi)) in enumerate(ranges):
+            g[lo:hi] = float(i + 1) * 0.5          # values exactly representable in bf16
+            ex.bucket_ready(tag)
+        ex.finish()
+        torch.cuda.synchronize()
+        want = torch.cat([torch.full((n // 8,), float(i + 1) * 0.5) for i in range(8)]).cuda()
+        assert torch.equal(g, want), kw
+    with pytest.raises(RuntimeError):
+        ex = E.ddp.GradExchange(ranges, overlap=True, single_rank_collectives=True)
+        ex.begin(torch.zeros(n, device='cuda'))
+        ex.bucket_ready('b0')
+        ex.finish()                                # seven buckets never reported
