@@ -24,6 +24,7 @@
 //     combination runs the same kernel with run-time flags.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 
 #define R_DMA_A(h, ring, soff)                                                                                                   \
     do {                                                                                                                         \
+        if (STAMP && (ablate & 2) && dma_off) break;                                                                             \
         char *dst_ = smem + (3 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                       \
         const int so_ = (soff) + (h) * 128 * lda2;                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)dst_, 16, voA0, so_, 0, 0);                                        \
@@ -371,6 +373,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     } while (0)
 #define R_DMA_B(h, ring, soff)                                                                                                   \
     do {                                                                                                                         \
+        if (STAMP && (ablate & 2) && dma_off) break;                                                                             \
         char *dst_ = smem + (6 + 2 * (h) + (ring)) * HALF_BYTES + wave * 2048;                                                   \
         const int so_ = (soff) + (h) * 128 * ldb2;                                                                               \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)dst_, 16, voB0, so_, 0, 0);                                        \
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         __builtin_amdgcn_sched_barrier(0); \
     } while (0)
 
+    [[maybe_unused]] bool dma_off = false;   // diagnostics (stamped builds): ablate 2 = no DMA pieces after the prologue, 4 = no counted waits
     int cm0, cn0, nm0, nn0;
     decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
     nm0 = cm0; nn0 = cn0;
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     bool a_ok = true, b_ok = true;
 #define R_ADV_A()                                                                                         \
     do {                                                                                                  \
+        if (STAMP && (ablate & 8) && dma_off) break;                                                      \
         if (++a_kt == nk) {                                                                               \
             a_kt = 0;                                                                                     \
             a_it += (int)gridDim.x;                                                                       \
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     } while (0)
 #define R_ADV_B()                                          \
     do {                                                   \
+        if (STAMP && (ablate & 8) && dma_off) break;       \
         if (++b_kt == nk) {                                \
             b_kt = 0;                                      \
             b_it += (int)gridDim.x;                        \
@@ -465,6 +471,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     }
     __builtin_amdgcn_s_barrier();
 
+    dma_off = true;
     int ga = 0, gb = 0;   // ring slots of the K-tile being multiplied
     bool pre = false;     // the coming K-tile's DMA pieces were issued ahead of the previous tile's epilogue
     // VMEM instructions the epilogue leaves in flight at least: its output stores (masked lanes still issue)
@@ -482,6 +489,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        // the K loop exists twice, once per wave group: which group a wave belongs to never changes, and as a run-time condition it cost
+        // six taken branches per K-tile
+        auto kloop = [&](auto late_c) __attribute__((always_inline)) {
+        constexpr bool LATE = decltype(late_c)::value;
         for (int kt = 0; kt < nk; ++kt) {
             const int sa = (3 * wm + ga) * HALF_BYTES + loff;          // byte offsets into smem (kept integral: LDS address space)
             const int sb = (6 + 2 * (wn >> 1) + gb) * HALF_BYTES + boff;
@@ -500,7 +511,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             // 1-4 of the next K-tile, the trailing group in quadrant 4 of this one and 1-3 of the next.
 #define R_BAR()                                                                  \
     do {                                                                         \
-        if (a_iss) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              \
+        if (STAMP && (ablate & 6)) { }                                           \
+        else if (a_iss) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
         else if (pre_k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                       \
@@ -518,7 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (s * 64)));
             if (!pre_k && b_ok) {
-                if (!late) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
+                if constexpr (!LATE) R_DMA_B(0, gb1, b_base + b_kt * (BK * 2));
                 else { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
             }
             R_PHASE_SYNC_A();
@@ -529,10 +541,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) b1[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (s * 64)));
-            if (!late) {
+            if constexpr (!LATE) {
                 if (!pre_k && b_ok) { R_DMA_B(1, gb1, b_base + b_kt * (BK * 2)); R_ADV_B(); }
-            } else if (a_iss) {
-                R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+            } else {
+                if (a_iss) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
             }
             R_PHASE_SYNC_A();
             R_QUAD(0, 2, b1);
@@ -543,28 +555,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #pragma unroll
                 for (int s = 0; s < 2; ++s) a[i][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (s * 64)));
             if (a_iss) {
-                if (!late) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
+                if constexpr (!LATE) R_DMA_A(0, ga2, a_base + a_kt * (BK * 2));
                 else { R_DMA_A(1, ga2, a_base + a_kt * (BK * 2)); R_ADV_A(); }
             }
             R_PHASE_SYNC_A();
             R_QUAD(4, 2, b1);
             R_PHASE_SYNC_B();
             // ---------------- quadrant 4: rows 64-127 x n-tiles 0,1 (no LDS reads)
-            if (late) {
+            if constexpr (LATE) {
                 R_BAR();
                 if (b_ok) R_DMA_B(0, gb, b_base + b_kt * (BK * 2));   // first half of B(kt+2), into the slot of B(kt)
-            } else if (a_iss) {
-                R_DMA_A(1, ga2, a_base + a_kt * (BK * 2));
-                R_ADV_A();
+            } else {
+                if (a_iss) { R_DMA_A(1, ga2, a_base + a_kt * (BK * 2)); R_ADV_A(); }
             }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
             R_QUAD(4, 0, b0);
             R_PHASE_SYNC_B();
-            if (!late) R_BAR();
+            if constexpr (!LATE) R_BAR();
             ga = ga == 2 ? 0 : ga + 1;
             gb ^= 1;
         }
+        };
+        if (late) kloop(std::true_type{});
+        else kloop(std::false_type{});
 #undef R_BAR
         // ---------------- output tile done; the epilogue runs straight from the accumulators (no LDS memory involved, so the operand
         // stream of the next tile stays in flight underneath and no barrier surrounds it).
@@ -657,7 +671,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #define NT_LAUNCH(TO, FL) hipLaunchKernelGGL((gemm_nt_kernel<TO, FL>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
 #ifdef ECGVIT_TOOLS
     if ((diag & 1) && d->out_dtype == ECGVIT_BF16) {   // stamped diagnostic instantiations; diag & 2: output stores dropped
-        const int ab = (diag >> 1) & 1;
+        const int ab = (diag >> 1) & 15;   // ablate bits: 1 stores dropped, 2 no DMA after the prologue, 4 no counted waits, 8 operand cursors frozen
         if (fl == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
         else if (fl == (F_UP | ECGVIT_EPI_DROPOUT)) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
         else if (fl == F_DH) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_DH, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);

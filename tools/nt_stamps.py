@@ -18,7 +18,7 @@ from ecg_representation_learning_amd.hip import (EPI_BIAS, EPI_GELU, EPI_DROPOUT
 
 
 COLD = '--cold' in sys.argv
-variants = [(0, 1), (0, 3)]   # (raster_g, diag): diag 1 = stamped build, 3 = stamped + output stores dropped
+variants = [(0, int(x)) for x in os.environ.get('NT_STAMP_DIAGS', '1,3').split(',')]   # (raster_g, diag): diag 1 = stamped build, +2 = output stores dropped, +4 = no DMA after the prologue, +8 = no counted waits
 
 
 def main():

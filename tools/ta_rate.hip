@@ -8,8 +8,9 @@
 //   mode 6: buffer_store_dwordx4, 8 rows x 128 B with the lanes of a line 8 apart (lane = 16 q + 8 half + row: an MFMA accumulator
 //           layout after a row_ror:8 exchange of the two half-line runs)
 //   mode 7 / 8: buffer_load_dwordx4 -> VGPR, 16 rows x 64 B / 8 rows x 128 B per wave-instruction (epilogue operand reads)
+//   mode 32 / 33: bare v_mfma_f32_16x16x32_bf16 / 32x32x16 loops on random operands (same MACs): FLOP/s at the power cap
 //   mode 16 + bits: the GEMM K-tile's instruction mix without its dependencies, per wave and sweep: bit 0 = 8 LDS-DMA pieces,
-//           bit 1 = 24 ds_read_b128, bit 2 = 64 v_mfma_f32_16x16x32_bf16
+//           bit 1 = 24 ds_read_b128, bit 2 = 64 v_mfma_f32_16x16x32_bf16, bit 3 = one s_barrier per sweep; LDS and register operands random
 // Every workgroup works on its own 64-KiB window (256 windows = 16 MiB: L2-resident on 8 x 4 MiB), `iters` sweeps of 64 wave-instructions.
 // Build + run (GPU box):  hipcc -O3 -w --offload-arch=gfx950 tools/ta_rate.hip -o gpurun_out/ta_rate && gpurun_out/ta_rate
 #include <hip/hip_runtime.h>
@@ -21,6 +22,7 @@
 typedef __attribute__((address_space(3))) void *lptr_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE, int THREADS>
@@ -42,6 +44,29 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
     else vo = lane * 16;                                                   // 1 KiB contiguous (= 8 rows x 128 B of a dense image)
     u32x4 acc = {0u, 0u, 0u, 0u};
     [[maybe_unused]] f32x4 macc[8] = {};
+    [[maybe_unused]] f32x16 macc16[2] = {};
+    [[maybe_unused]] f32x4 bacc[MODE >= 50 ? 8 : 1][4] = {};
+    [[maybe_unused]] bf16x8 rnd[4];
+    {   // pseudo-random bf16 operands in [-2, 2): exponent bits from a small set, random mantissas
+        unsigned h = (unsigned)(threadIdx.x * 2654435761u) ^ (unsigned)(blockIdx.x * 40503u + 12345u);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u32x4 w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+                w[k] = (h & 0x807F807Fu) | 0x3F803F80u;   // sign + 7 mantissa bits random, exponent of 1.0
+            }
+            rnd[q] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    if (MODE >= 16) {   // random bf16 contents for the fragment reads (the matrix pipe's power depends on its operands)
+        unsigned h = (unsigned)(threadIdx.x * 2654435761u) ^ 0x9E3779B9u;
+        for (int i = threadIdx.x; i < 16384; i += THREADS) {
+            h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+            reinterpret_cast<unsigned *>(smem)[i] = (h & 0x807F807Fu) | 0x3F803F80u;
+        }
+    }
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
@@ -95,6 +120,78 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
             }
 #pragma unroll
             for (int p = 0; p < PER_WAVE; ++p) acc ^= r[p];
+        } else if constexpr (MODE == 32 || MODE == 33) {
+            // bare MFMA loops on random register operands (the power the matrix pipe draws depends on the data): 64 x 16x16x32 or
+            // 32 x 32x32x16 per wave and sweep = the same 2^20 MACs
+            if constexpr (MODE == 32) {
+#pragma unroll
+                for (int k = 0; k < 64; ++k) macc[k & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rnd[k & 3], rnd[(k + 1) & 3], macc[k & 7], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 32; ++k) macc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rnd[k & 3], rnd[(k + 1) & 3], macc16[k & 1], 0, 0, 0);
+            }
+        } else if constexpr (MODE >= 50 && MODE <= 53) {
+            // gemm_nt_kernel's K-tile without its DMA: 128 accumulators, quadrants of 16 MFMAs, fragment reads 12 / 4 / 8 / 0.
+            //   50: compiler-scheduled   51: + explicit lgkmcnt(0), sched barriers and s_setprio around each MFMA cluster
+            //   52: 51 + one barrier per K-tile, waves 4-7 passing it before quadrant 4 (the shipped arrangement)   53: 52 without s_setprio
+            constexpr bool EXPL = MODE >= 51, BAR = MODE >= 52, PRIO = MODE == 51 || MODE == 52;
+            const int fr = lane & 15, fq = lane >> 4;
+            const int base = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+            const int sa = (wave >> 2) * 16384 + base, sb = 32768 + ((wave & 3) >> 1) * 16384 + ((wave & 1) * 8192) + base;
+            bf16x8 a[4][2], b0[2][2], b1[2][2];
+            const bool latew = wave >= 4;
+#define T_SYNC_A() do { if (EXPL) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); if (PRIO) __builtin_amdgcn_s_setprio(1); } } while (0)
+#define T_SYNC_B() do { if (EXPL) { if (PRIO) __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define T_QUAD(IO, JO, BF) do { _Pragma("unroll") for (int ss = 0; ss < 2; ++ss) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+                bacc[IO + i][JO + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][ss], a[i][ss], bacc[IO + i][JO + j], 0, 0, 0); } while (0)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) b0[j][ss] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + j * 512) ^ (ss * 64)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) a[i][ss] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + i * 2048) ^ (ss * 64)));
+            T_SYNC_A(); T_QUAD(0, 0, b0); T_SYNC_B();
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) b1[j][ss] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + 4096 + j * 512) ^ (ss * 64)));
+            T_SYNC_A(); T_QUAD(0, 2, b1); T_SYNC_B();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) a[i][ss] = *reinterpret_cast<const bf16x8 *>(smem + ((sa + (4 + i) * 2048) ^ (ss * 64)));
+            T_SYNC_A(); T_QUAD(4, 2, b1); T_SYNC_B();
+            if (BAR && latew) __builtin_amdgcn_s_barrier();
+            if (EXPL) { __builtin_amdgcn_sched_barrier(0); if (PRIO) __builtin_amdgcn_s_setprio(1); }
+            T_QUAD(4, 0, b0); T_SYNC_B();
+            if (BAR && !latew) __builtin_amdgcn_s_barrier();
+#undef T_SYNC_A
+#undef T_SYNC_B
+#undef T_QUAD
+        } else if constexpr (MODE == 40 || MODE == 41) {
+            // the GEMM's issue pattern: two pieces per quadrant; the sweep's counted wait covers the pieces of ITS first two quadrants
+            // (mode 40: what a one-K-tile-ahead operand gets) or only pieces of the sweep before (mode 41: two K-tiles ahead)
+            bf16x8 f[6];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    const int fr = lane & 15, fq = lane >> 4;
+                    f[k] = *reinterpret_cast<const bf16x8 *>(smem + ((wave * 4 + g) & 31) * 2048 + fr * 128 + (((fq + 2 * k) & 7) ^ ((fr >> 1) & 7)) * 16);
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int piece = (wave * 8 + g * 2 + p + it) & 63;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + (wave * 8 + g * 2 + p) * 1024), 16, vo, piece * 1024, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) macc[k & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[k % 6], f[(k + 1) % 6], macc[k & 7], 0, 0, 0);
+            }
+            if constexpr (MODE == 40) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         } else if constexpr (MODE >= 16) {
             static_assert(MODE < 16 || THREADS == 512, "mix modes: 8 waves");
             if constexpr (MODE & 1) {
@@ -115,7 +212,7 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) f[k] = __builtin_bit_cast(bf16x8, acc);
+                    for (int k = 0; k < 6; ++k) f[k] = rnd[k & 3];
                 }
                 if constexpr (MODE & 4) {
 #pragma unroll
@@ -126,6 +223,7 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
                 }
             }
             if constexpr (MODE & 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if constexpr ((MODE & 8) != 0) __builtin_amdgcn_s_barrier();   // + the K-tile's workgroup barrier
         } else {
             const u32x4 v = {(unsigned)it, (unsigned)lane, 3u, 4u};
 #pragma unroll
@@ -146,13 +244,20 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
     if (MODE >= 16) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[0] ^= __builtin_bit_cast(u32x4, macc[k])[k & 3];
+        acc[1] ^= __builtin_bit_cast(unsigned, macc16[0][3]) ^ __builtin_bit_cast(unsigned, macc16[1][5]);
+        if constexpr (MODE >= 50) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[(i + j) & 3] ^= __builtin_bit_cast(u32x4, bacc[i][j])[(i * j) & 3];
+        }
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[0] = 1;
 }
 
 template <int MODE, int THREADS>
 static void run(const char *name, char *buf, unsigned long long *dcyc, unsigned *sink, int nwg) {
-    const int iters = 2000;
+    const int iters = MODE >= 32 ? 200000 : (MODE == 20 || MODE == 22 || MODE == 23 || MODE == 21 || MODE == 31 || MODE == 28 || MODE == 40 || MODE == 41) ? 100000 : 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     ta_rate_kernel<MODE, THREADS><<<nwg, THREADS>>>(buf, 50, dcyc, sink);
@@ -199,6 +304,10 @@ int main() {
         run<10, 512>("load dwordx4, 16 x 64 B, quads adjacent", buf, dcyc, sink, nwg);
         run<11, 512>("64 ds_bpermute_b32 per wave and sweep", buf, dcyc, sink, nwg);
         run<12, 512>("store 8 x 128 B after bpermute+DPP transposition", buf, dcyc, sink, nwg);
+        run<32, 512>("bare MFMA 16x16x32 bf16, random operands (2^20 MACs per wave and sweep)", buf, dcyc, sink, nwg);
+        run<33, 512>("bare MFMA 32x32x16 bf16, random operands (2^20 MACs per wave and sweep)", buf, dcyc, sink, nwg);
+        run<32, 256>("bare MFMA 16x16x32 bf16, random operands, 4 waves", buf, dcyc, sink, nwg);
+        run<33, 256>("bare MFMA 32x32x16 bf16, random operands, 4 waves", buf, dcyc, sink, nwg);
         run<17, 512>("mix: DMA", buf, dcyc, sink, nwg);
         run<18, 512>("mix: ds_read", buf, dcyc, sink, nwg);
         run<20, 512>("mix: MFMA", buf, dcyc, sink, nwg);
@@ -206,6 +315,14 @@ int main() {
         run<21, 512>("mix: DMA + MFMA", buf, dcyc, sink, nwg);
         run<22, 512>("mix: ds_read + MFMA", buf, dcyc, sink, nwg);
         run<23, 512>("mix: DMA + ds_read + MFMA", buf, dcyc, sink, nwg);
+        run<31, 512>("mix: DMA + ds_read + MFMA + one s_barrier per sweep", buf, dcyc, sink, nwg);
+        run<28, 512>("mix: MFMA + one s_barrier per sweep", buf, dcyc, sink, nwg);
+        run<50, 512>("K-tile skeleton (128 accumulators, 12/4/8/0 reads), compiler-scheduled", buf, dcyc, sink, nwg);
+        run<51, 512>("K-tile skeleton + explicit waits, sched barriers, s_setprio", buf, dcyc, sink, nwg);
+        run<52, 512>("K-tile skeleton + those + one barrier per K-tile (waves 4-7 before quadrant 4)", buf, dcyc, sink, nwg);
+        run<53, 512>("K-tile skeleton as 52 without s_setprio", buf, dcyc, sink, nwg);
+        run<40, 512>("mix: all, 2 pieces per quadrant, wait covers this sweep's first 4 pieces", buf, dcyc, sink, nwg);
+        run<41, 512>("mix: all, 2 pieces per quadrant, wait covers the previous sweep's pieces", buf, dcyc, sink, nwg);
     }
     return 0;
 }
