@@ -45,7 +45,8 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
     u32x4 acc = {0u, 0u, 0u, 0u};
     [[maybe_unused]] f32x4 macc[8] = {};
     [[maybe_unused]] f32x16 macc16[2] = {};
-    [[maybe_unused]] f32x4 bacc[MODE >= 50 ? 8 : 1][4] = {};
+    [[maybe_unused]] f32x4 bacc[(MODE >= 50 && MODE < 60) ? 8 : 1][4] = {};
+    [[maybe_unused]] f32x4 wacc[(MODE == 60 || MODE == 61) ? 8 : 1][MODE == 61 ? 8 : 4] = {};
     [[maybe_unused]] bf16x8 rnd[4];
     {   // pseudo-random bf16 operands in [-2, 2): exponent bits from a small set, random mantissas
         unsigned h = (unsigned)(threadIdx.x * 2654435761u) ^ (unsigned)(blockIdx.x * 40503u + 12345u);
@@ -130,6 +131,32 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
 #pragma unroll
                 for (int k = 0; k < 32; ++k) macc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rnd[k & 3], rnd[(k + 1) & 3], macc16[k & 1], 0, 0, 0);
             }
+        } else if constexpr (MODE == 60 || MODE == 61) {
+            // one K-tile of a 256 x 256 x 64 block tile per sweep, with its operand pieces (64 KiB by LDS-DMA from the L2-resident window),
+            // compiler-scheduled, random operands:  60 = 8 waves x (128 x 64) wave tiles (192 KiB of fragment reads per K-tile),
+            //                                        61 = 4 waves x (128 x 128) wave tiles (128 KiB), 256 accumulator registers per lane
+            constexpr int NJ = MODE == 60 ? 4 : 8, NP = MODE == 60 ? 8 : 16;
+            const int fr = lane & 15, fq = lane >> 4;
+            const int base = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int piece = (wave * NP + p + it) & 63;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(smem + (wave * NP + p) * 1024), 16, vo, piece * 1024, 0, 0);
+            }
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                bf16x8 a[8], b[NJ];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const bf16x8 *>(smem + (((wave & 1) * 16384 + i * 2048 + base) ^ (ss * 64)));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *reinterpret_cast<const bf16x8 *>(smem + ((32768 + ((wave >> 1) & 1) * 16384 + j * 2048 + base) ^ (ss * 64)));
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) wacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], wacc[i][j], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP / 2) : "memory");
+            __builtin_amdgcn_s_barrier();
         } else if constexpr (MODE >= 50 && MODE <= 53) {
             // gemm_nt_kernel's K-tile without its DMA: 128 accumulators, quadrants of 16 MFMAs, fragment reads 12 / 4 / 8 / 0.
             //   50: compiler-scheduled   51: + explicit lgkmcnt(0), sched barriers and s_setprio around each MFMA cluster
@@ -245,11 +272,17 @@ __global__ __launch_bounds__(THREADS) void ta_rate_kernel(char *buf, int iters, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[0] ^= __builtin_bit_cast(u32x4, macc[k])[k & 3];
         acc[1] ^= __builtin_bit_cast(unsigned, macc16[0][3]) ^ __builtin_bit_cast(unsigned, macc16[1][5]);
-        if constexpr (MODE >= 50) {
+        if constexpr (MODE >= 50 && MODE < 60) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[(i + j) & 3] ^= __builtin_bit_cast(u32x4, bacc[i][j])[(i * j) & 3];
+        }
+        if constexpr (MODE == 60 || MODE == 61) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < (MODE == 61 ? 8 : 4); ++j) acc[(i + j) & 3] ^= __builtin_bit_cast(u32x4, wacc[i][j])[(i * j) & 3];
         }
     }
     if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345u) sink[0] = 1;
@@ -317,6 +350,8 @@ int main() {
         run<23, 512>("mix: DMA + ds_read + MFMA", buf, dcyc, sink, nwg);
         run<31, 512>("mix: DMA + ds_read + MFMA + one s_barrier per sweep", buf, dcyc, sink, nwg);
         run<28, 512>("mix: MFMA + one s_barrier per sweep", buf, dcyc, sink, nwg);
+        run<60, 512>("256x256x64 K-tile, 8 waves x 128x64, DMA + reads + MFMA + barrier", buf, dcyc, sink, nwg);
+        run<61, 256>("256x256x64 K-tile, 4 waves x 128x128, DMA + reads + MFMA + barrier", buf, dcyc, sink, nwg);
         run<50, 512>("K-tile skeleton (128 accumulators, 12/4/8/0 reads), compiler-scheduled", buf, dcyc, sink, nwg);
         run<51, 512>("K-tile skeleton + explicit waits, sched barriers, s_setprio", buf, dcyc, sink, nwg);
         run<52, 512>("K-tile skeleton + those + one barrier per K-tile (waves 4-7 before quadrant 4)", buf, dcyc, sink, nwg);
