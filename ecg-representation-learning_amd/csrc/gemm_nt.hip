@@ -415,18 +415,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             }                                                                                                                    \
         }                                                                                                                        \
     } while (0)
-    // a quadrant = its fragment reads (and up to two DMA pieces), one LDS wait, 16 MFMAs at raised priority; NO workgroup barrier
-#define R_PHASE_SYNC_A()                                   \
-    do {                                                   \
-        __builtin_amdgcn_sched_barrier(0);                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                 \
-        __builtin_amdgcn_s_setprio(1);                     \
+    // a quadrant = its fragment reads (and up to two DMA pieces) and 16 MFMAs, scheduled by the compiler: its counted lgkmcnt waits
+    // let a cluster's first MFMAs start before the last fragment has arrived, and it may hoist the next quadrant's reads into the
+    // cluster.  Explicit `lgkmcnt(0)` + sched barriers + s_setprio around every cluster measured 1.5 % slower per launch inside the step
+    // (profiles/r02_nt_compiler_scheduled.txt).  No workgroup barrier here: the K-tile's one barrier is R_BAR, fenced on both sides.
+    // The 8-bit instantiations (half as many, longer MFMAs per cluster) keep the explicit form: it measured 1.3 % faster per launch there.
+#define R_PHASE_SYNC_A()                                       \
+    do {                                                       \
+        if constexpr (OPS != 0) {                              \
+            __builtin_amdgcn_sched_barrier(0);                 \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+            __builtin_amdgcn_sched_barrier(0);                 \
+            __builtin_amdgcn_s_setprio(1);                     \
+        }                                                      \
     } while (0)
-#define R_PHASE_SYNC_B()                   \
-    do {                                   \
-        __builtin_amdgcn_s_setprio(0);     \
-        __builtin_amdgcn_sched_barrier(0); \
+#define R_PHASE_SYNC_B()                       \
+    do {                                       \
+        if constexpr (OPS != 0) {              \
+            __builtin_amdgcn_s_setprio(0);     \
+            __builtin_amdgcn_sched_barrier(0); \
+        }                                      \
     } while (0)
 
     [[maybe_unused]] bool dma_off = false;   // diagnostics (stamped builds): ablate 2 = no DMA pieces after the prologue, 4 = no counted waits
@@ -524,7 +532,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) b0[j][s] = *reinterpret_cast<const bf16x8 *>(smem + ((sb + j * 512) ^ (s * 64)));
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -568,8 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             } else {
                 if (a_iss) { R_DMA_A(1, ga2, a_base + a_kt * (BK * 2)); R_ADV_A(); }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
+            if constexpr (OPS != 0) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
             R_QUAD(4, 0, b0);
             R_PHASE_SYNC_B();
             if constexpr (!LATE) R_BAR();
