@@ -4,6 +4,8 @@ bench.py -- 12-lead ECG records/sec for one train step of EcgVit (BASELINE.json 
 
   python bench.py --gpus 1 --steps K --warmup W                         (single process)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: the parent starts N rank processes itself, before touching the GPU, relays
+                                       rank 0's JSON line and exits non-zero if any rank failed)
 
 A "step" = the reference's step body (ecg_transformer/models/train.py:271-283) on one synthetic batch already
 resident in HBM: forward (patch-embed -> L x [LN, MHSA, LN, GELU-FFN] -> head) + BCE loss + backward + global-norm
@@ -69,9 +71,10 @@ class GemmProbe:
         probe = self
 
         def gemm(layout, A, B, C, M, N, K, *a, **k):
+            # which kernel symbol this call runs on is the LIBRARY's answer (ecgvit_gemm_kernel: its own dispatch, nothing launched)
+            hit = probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and \
+                probe.hip.gemm_kernel(layout, A, B, C, M, N, K, *a, **k) == probe.hip.KERNEL_GEMM_NT
             f8 = k.get('fp8_format') is not None
-            hit = (probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and (A.dtype == torch.bfloat16 or f8)
-                   and K % 64 == 0 and K >= 192 and M >= 2048 and N >= 128)   # = ecgvit_gemm_nt_applicable: the launches of gemm_nt_kernel
             if hit:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -110,25 +113,36 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def workload_key(args):
+    """identifies the workload a counter profile was taken on (profiles/*.json carry it next to the kernel-source hash)"""
+    _, batch = CONFIGS[args.config]
+    drop = 'default' if args.dropout is None else f'{args.dropout:g}'
+    return f'{args.config}-{args.dtype}-b{args.batch or batch}-p{args.patch}-l{args.length}-drop{drop}-{args.objective}'
+
+
 def pmc_traffic(kernel_key, args):
     """(HBM bytes per launch of the dominant kernel, where that number comes from).  Counters cannot be read from inside the
-    process: the value is the one the committed rocprofv3 --pmc passes measured on this command line (tools/pmc_bench.sh:
+    process: the value is the one a committed rocprofv3 --pmc profile measured on this workload (tools/pmc_bench.sh:
     2 x FETCH_SIZE per the gfx950 calibration + WRITE_SIZE) -- reported only while the kernel sources are the ones profiled."""
-    if args.config != 'base' or args.dtype != 'bf16' or args.batch not in (None, 512):
-        return None, 'none: not the profiled workload'
-    name = 'r02_pmc_base_b512.json' if args.objective == 'supervised' else 'r02_pmc_base_b512_masked.json'
-    path = os.path.join(ROOT, 'profiles', name)
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-    except Exception:
-        return None, f'none: profiles/{name} not found'
-    if prof.get('kernel_source_sha16') != kernel_source_hash():
-        return None, f'none: kernel sources changed since profiles/{name} (taken on sources {prof.get("kernel_source_sha16")})'
-    try:
-        return prof['kernels'][kernel_key]['hbm_bytes_per_launch'], f'profiles/{name} @ sources {prof["kernel_source_sha16"]}'
-    except KeyError:
-        return None, f'none: profiles/{name} has no entry for {kernel_key}'
+    key, sha = workload_key(args), kernel_source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_*.json')), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+        except Exception:
+            continue
+        if prof.get('workload_key') != key:
+            continue
+        name = os.path.basename(path)
+        if prof.get('kernel_source_sha16') != sha:
+            stale = stale or f'none: kernel sources changed since profiles/{name} (taken on sources {prof.get("kernel_source_sha16")})'
+            continue
+        try:
+            return prof['kernels'][kernel_key]['hbm_bytes_per_launch'], f'profiles/{name} @ sources {sha}'
+        except KeyError:
+            return None, f'none: profiles/{name} has no entry for {kernel_key}'
+    return None, stale or f'none: no counter profile of workload {key} under profiles/'
 
 
 def cpu_baseline(conf, seconds_budget=25.0, masked=False):
@@ -189,7 +203,7 @@ def cpu_baseline(conf, seconds_budget=25.0, masked=False):
                 tflops=b * n * flops_rec / dt / 1e12)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -207,15 +221,56 @@ def main():
     ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
     ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
     ap.add_argument('--single-rank-collectives', action='store_true',
-                    help='diagnostic, --gpus 1 only: a 1-rank RCCL group with the N > 1 code path switched on (start broadcast, per-bucket '
-                         'all-reduces overlapped with backward, chunked GEMM launches): what the data-parallel machinery costs without a wire')
+                    help='diagnostic, --gpus 1 only: a 1-rank RCCL group with the N > 1 code path switched on (self-launcher, start broadcast, '
+                         'per-bucket all-reduces overlapped with backward, chunked GEMM launches): what the data-parallel machinery costs without a wire')
     ap.add_argument('--grad-comm', choices=['f32', 'bf16'], default='f32', help='dtype of the gradient buckets on the wire (N > 1)')
-    args = ap.parse_args()
+    ap.add_argument('--hip-lib', default=None, help='measurement only: load another build of the same C-ABI (A/B candidate, tools build)')
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this same command (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), relay rank 0's stdout, fail if any rank fails.
+    Runs BEFORE anything in this process touches the GPU, starts children (never replaces this process image) and returns the exit code."""
+    import subprocess
+    n = args.gpus
+    env = dict(os.environ)
+    env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode(errors='replace'))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
+        return 1
+    return 0
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.single_rank_collectives):
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch N ranks, or run without a launcher)')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1 or args.single_rank_collectives:
@@ -223,7 +278,13 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        rccl_ranks = dist.get_world_size()
+    else:
+        rccl_ranks = 0
 
+    if args.hip_lib:
+        from ecg_representation_learning_amd import hip as _hip
+        _hip.use_library(args.hip_lib)
     import ecg_representation_learning_amd as E
     E.hip.lib()  # fail loudly if the HIP library is missing
 
@@ -237,6 +298,8 @@ def main():
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
+
+    rank_times = {}
 
     def timed_run(objective, steps, warmup):
         """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result)"""
@@ -271,13 +334,17 @@ def main():
         if probe:
             probe.enabled = False
             probe.uninstall()
-        if world > 1:
+        rank_dt = [dt]
+        if world > 1 or args.single_rank_collectives:
             import torch.distributed as dist
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            rank_dt = [float(e.item()) for e in every]
+            dt = max(rank_dt)          # MAX over ranks
         final_loss = float(loss)
         step.finish()
+        rank_times[objective] = [1e3 * d / steps for d in rank_dt]
         return dt, final_loss, (probe.result() if probe else None)
 
     def roofline_of(r, objective):
@@ -329,6 +396,9 @@ def main():
                 'hidden': conf.hidden_size, 'layers': conf.num_hidden_layers, 'heads': conf.num_attention_heads,
             },
             'final_loss': final_loss,
+            'workload_key': workload_key(args), 'kernel_source_sha16': kernel_source_hash(),
+            'rccl_ranks': rccl_ranks,   # size of the RCCL process group the step exchanged gradients over (0 = no group: plain single-GPU step)
+            'rank_ms_per_step': rank_times[args.objective],
             'model_tflops_per_gpu': value / world * flops_rec / 1e12,
             'mfma_frac_of_peak': value / world * flops_rec / 1e12 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS),
         }

@@ -893,6 +893,7 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
                          uint64_t seed, int dtype, void *stream) {
     if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) % 16) return ECGVIT_EINVAL;
+    if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
     dim3 grid((unsigned)(B * h));
@@ -919,6 +920,7 @@ static int attention_bwd_args_ok(const void *qkv, const void *out, const void *d
 int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
                                  int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype) || N > 256) return ECGVIT_EINVAL;
+    if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
     dim3 grid((unsigned)(B * h));
@@ -935,6 +937,7 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype)) return ECGVIT_EINVAL;
     if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31))   // short sequences / 32-bit buffer offsets exhausted
         return ecgvit_attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
+    if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
     const int nitems = B * h;

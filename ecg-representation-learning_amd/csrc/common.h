@@ -223,6 +223,7 @@ static inline EpiParams make_epi(const ecgvit_gemm_desc *d) {
     return e;
 }
 
-// internal launchers (defined in gemm_f32.hip / gemm_bf16.hip)
-int ecgvit_gemm_f32_launch(const ecgvit_gemm_desc *d, hipStream_t s);
-int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s);
+// internal launchers (defined in gemm_f32.hip / gemm_bf16.hip).  route != nullptr: launch nothing, report the kernel family
+// (ECGVIT_KERNEL_*) the same arguments would run on -- one dispatch, whether it is executed or asked about (ecgvit_gemm_kernel)
+int ecgvit_gemm_f32_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route = nullptr);
+int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route = nullptr);

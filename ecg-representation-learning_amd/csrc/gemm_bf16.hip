@@ -315,7 +315,7 @@ extern "C" int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d) {
     return std::max(v1, ecgvit_gemm_wgrad_workspace(d));
 }
 
-int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
+int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route) {
     if (d->dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
     if (d->out_dtype != ECGVIT_BF16 && d->out_dtype != ECGVIT_F32) return ECGVIT_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
@@ -331,8 +331,16 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
     if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
 
-    if (ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, s, 0, 0);
-    if (ecgvit_gemm_wgrad_applicable(d)) return ecgvit_gemm_wgrad_launch(d, s);
+    if (d->layout != ECGVIT_GEMM_NT && d->layout != ECGVIT_GEMM_NN && d->layout != ECGVIT_GEMM_TN) return ECGVIT_EINVAL;
+    if (ecgvit_gemm_nt_applicable(d)) {
+        if (route) { *route = ECGVIT_KERNEL_GEMM_NT; return ECGVIT_OK; }
+        return ecgvit_gemm_nt_launch(d, s, 0, 0);
+    }
+    if (ecgvit_gemm_wgrad_applicable(d)) {
+        if (route) { *route = ECGVIT_KERNEL_GEMM_WGRAD; return ECGVIT_OK; }
+        return ecgvit_gemm_wgrad_launch(d, s);
+    }
+    if (route) { *route = ECGVIT_KERNEL_GEMM_BF16; return ECGVIT_OK; }
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     SplitK sk;
     sk.splits = 1;
@@ -371,31 +379,43 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     return ECGVIT_OK;
 }
 
-extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) {
+// the one dispatch of ecgvit_gemm: executed (route == nullptr) or only asked about (route receives ECGVIT_KERNEL_*)
+static int gemm_dispatch(const ecgvit_gemm_desc *d, void *stream, int *route) {
     if (!d) return ECGVIT_EINVAL;
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
-        if (d->dtype == ECGVIT_BF16 && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream));   // fused column sums
-        if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_nt_launch(d, as_stream(stream), 0, 0);
+        if (d->dtype == ECGVIT_BF16 && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream), route);   // fused column sums
+        if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && ecgvit_gemm_nt_applicable(d)) {
+            if (route) { *route = ECGVIT_KERNEL_GEMM_NT; return ECGVIT_OK; }
+            return ecgvit_gemm_nt_launch(d, as_stream(stream), 0, 0);
+        }
         // generic path: plain GEMM, then the stand-alone column-sum kernel over the stored output
         if (d->workspace_bytes < ecgvit_colsum_workspace(d->M, d->N)) return ECGVIT_EINVAL;
         ecgvit_gemm_desc g = *d;
         g.epilogue &= ~ECGVIT_EPI_COLSUM;
-        const int rc = ecgvit_gemm(&g, stream);
-        if (rc != ECGVIT_OK) return rc;
+        const int rc = gemm_dispatch(&g, stream, route);
+        if (rc != ECGVIT_OK || route) return rc;
         return ecgvit_colsum(d->C, d->ldc, d->colsum_out, d->workspace, d->M, d->N, d->out_dtype, stream);
     }
-    if (d->dtype == ECGVIT_F32) return ecgvit_gemm_f32_launch(d, as_stream(stream));
-    if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream));
+    if (d->dtype == ECGVIT_F32) return ecgvit_gemm_f32_launch(d, as_stream(stream), route);
+    if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream), route);
     if (d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) {   // 8-bit operands: the large A . B^T kernel only (no small-shape fallback)
         if (!d->A || !d->B || !d->C || (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16) return ECGVIT_EINVAL;
         if ((d->epilogue & ECGVIT_EPI_BIAS) && (!d->bias || reinterpret_cast<uintptr_t>(d->bias) % 16)) return ECGVIT_EINVAL;
         if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
         if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;
         if (d->ldc % 8 != 0 || !ecgvit_gemm_nt_applicable(d)) return ECGVIT_EINVAL;
+        if (route) { *route = ECGVIT_KERNEL_GEMM_NT; return ECGVIT_OK; }
         return ecgvit_gemm_nt_launch(d, as_stream(stream), 0, 0);
     }
     return ECGVIT_EINVAL;
+}
+
+extern "C" int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream) { return gemm_dispatch(d, stream, nullptr); }
+
+extern "C" int ecgvit_gemm_kernel(const ecgvit_gemm_desc *d) {
+    int route = ECGVIT_KERNEL_NONE;
+    return gemm_dispatch(d, nullptr, &route) == ECGVIT_OK ? route : ECGVIT_KERNEL_NONE;
 }
 
 #ifdef ECGVIT_TOOLS

@@ -142,13 +142,18 @@ inline bool vec_ok(const void *p, int64_t ld, int64_t s1, int64_t s2) {
 
 }  // namespace
 
-int ecgvit_gemm_f32_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
+int ecgvit_gemm_f32_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route) {
     if (d->dtype != ECGVIT_F32 || d->out_dtype != ECGVIT_F32) return ECGVIT_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K < 0 || d->batch1 < 1 || d->batch2 < 1) return ECGVIT_EINVAL;
     const int64_t nz = (int64_t)d->batch1 * d->batch2;
     if (nz > 65535) return ECGVIT_EINVAL;
     if (nz > 1 && (d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_RESIDUAL | ECGVIT_EPI_DROPOUT)))
         return ECGVIT_EINVAL;
+    if (route) {
+        if (d->layout != ECGVIT_GEMM_NT && d->layout != ECGVIT_GEMM_NN && d->layout != ECGVIT_GEMM_TN) return ECGVIT_EINVAL;
+        *route = ECGVIT_KERNEL_GEMM_F32;
+        return ECGVIT_OK;
+    }
     dim3 grid((d->N + BN - 1) / BN, (d->M + BM - 1) / BM, (unsigned)nz), block(256);
     EpiParams e = make_epi(d);
     const bool va = vec_ok(d->A, d->lda, d->strideA1, d->strideA2), vb = vec_ok(d->B, d->ldb, d->strideB1, d->strideB2);

@@ -380,7 +380,7 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
     return ECGVIT_OK;
 }
 
-const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi2"; }
-int ecgvit_abi_version(void) { return 2; }
+const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi3"; }
+int ecgvit_abi_version(void) { return 3; }
 
 }  // extern "C"

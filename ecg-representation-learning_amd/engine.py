@@ -93,6 +93,10 @@ class VitEngine:
                 raise ValueError(f'bf16 fused attention needs head dim 64 (got {self.dh}); use dtype=torch.float32')
             if self.N > 512:
                 raise ValueError(f'bf16 fused attention covers <= 512 tokens (got {self.N}); use dtype=torch.float32')
+            if 0.0 < self.p_hidden < 1.0 / 512:
+                # the fused attention kernels draw 8 random bits per key: p is applied as round(256 p) / 256 (0.1 -> 0.1016)
+                raise ValueError(f'bf16 fused attention applies dropout in steps of 1/256: hidden_dropout_prob={self.p_hidden} would round '
+                                 f'to no dropout; use 0, a value >= 1/512, or compute_dtype=torch.float32 (exact p)')
         # fp8 Linear operands (BASELINE.json configs[4]): the four block Linears' forward and input-gradient products take e4m3 / e5m2
         # operands (per-tensor scales, delayed for activations and gradients); weight gradients, attention, LayerNorm stay bf16
         self.fp8 = bool(fp8_linear)
@@ -110,6 +114,12 @@ class VitEngine:
         self.saved = None
         self.input_transform = None  # FusedInputTransform: forward() then takes RAW (B, C, L_raw) records
         self.on_grads_ready = None   # callback(tag): a gradient bucket ('head' | 'layer{i}' | 'embed' | 'pretrain') is final
+        self._tpw = 0                # ecgvit_gemm_desc.tiles_per_workgroup of the launches in flight (set by backward(..., tiles_per_workgroup=))
+
+    def _gemm(self, *a, **kw):
+        """every product of this engine: `tiles_per_workgroup` is per-engine, per-pass state (never a process-wide setting)"""
+        kw.setdefault('tiles_per_workgroup', self._tpw)
+        hip.gemm(*a, **kw)
 
     # ---------------------------------------------------------------- buffers
     def bind(self, pflat, gflat, wlow=None, wlow_t=None):
@@ -199,7 +209,7 @@ class VitEngine:
         emit_site: the site that consumes C next (its 8-bit copy is then written by this epilogue); prequant: A's copy is already in q8b.
         Returns True when the 8-bit copy of C was emitted."""
         if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
-            hip.gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
+            self._gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
             return False
         if prequant:   # the producer already wrote A's 8-bit copy: 'q8' (LayerNorm) or q8b (a GEMM epilogue)
             q, sc = self.act['q8' if prequant == 'q8' else 'q8b'][:M * K], self.f8_scale[site:site + 1]
@@ -207,7 +217,7 @@ class VitEngine:
             q, sc = self._quant(site, A, M * K)
         emitted = emit_site is not None and self._emit8(kw, emit_site, N)
         mi = self.w8_index[name]
-        hip.gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
+        self._gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
         return emitted
 
     def transposed_weight_names(self):
@@ -242,14 +252,14 @@ class VitEngine:
                 q, sc = self._quant(site, dY, M * nout)
             emitted = emit_site is not None and self._emit8(kw, emit_site, kin)
             mi = self.w8_index[name]
-            hip.gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
+            self._gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
                      scale_b=self.w8_scale[mi:mi + 1], **kw)
             return emitted
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
-            hip.gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
+            self._gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
         else:
-            hip.gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
+            self._gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
 
     def _alloc(self, B, masked=False, m=0):
         key = (B, masked, m)
@@ -329,7 +339,7 @@ class VitEngine:
 
     def _wgrad(self, dY, X, name, Mout, Nin, rows):
         """dW[Mout, Nin] = dY[rows, Mout]^T . X[rows, Nin]  -> f32 gradient view (overwritten)"""
-        hip.gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
+        self._gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
 
     # ---------------------------------------------------------------- forward
     def _patch_embed(self, x, B):
@@ -347,7 +357,7 @@ class VitEngine:
                                                       ptr(inv_std), ptr(t0), ptr(tl), T, stream()), 'patch_gather_transform')
         else:
             check(lib().ecgvit_patch_gather(ptr(x), ptr(a['patches']), B, self.C, self.L, self.P, self.CP, T, stream()), 'patch_gather')
-        hip.gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], B * self.n, self.d, self.CP, self.CP,
+        self._gemm(GEMM_NT, a['patches'], W[pre + 'to_patch_embedding.1.weight'], a['tok'], B * self.n, self.d, self.CP, self.CP,
                  self.CP, self.d, epilogue=EPI_BIAS, bias=self.P32[pre + 'to_patch_embedding.1.bias'])
 
     def _trunk_fwd(self, B, ph, seed):
@@ -446,7 +456,7 @@ class VitEngine:
         X = self._trunk_fwd(B, ph, seed)
         self.saved['xL'] = X
         check(l.ecgvit_gather_rows(ptr(X), ptr(idx), ptr(a['rows']), B, n, m, d, d, d, T, st), 'gather_rows')
-        hip.gemm(GEMM_NT, a['rows'], W['pretrain.to_pixels.weight'], a['pred'], B * m, self.CP, d, d, d, self.CP, epilogue=EPI_BIAS,
+        self._gemm(GEMM_NT, a['rows'], W['pretrain.to_pixels.weight'], a['pred'], B * m, self.CP, d, d, d, self.CP, epilogue=EPI_BIAS,
                  bias=self.P32['pretrain.to_pixels.bias'])
         check(l.ecgvit_gather_rows(ptr(a['patches']), ptr(idx), ptr(a['target']), B, n, m, self.CP, self.CP, self.CP, T, st), 'gather_rows')
         # L1 loss and d(loss)/d(pred) in one pass (upstream gradient 1; backward_masked re-runs it for any other upstream)
@@ -454,8 +464,16 @@ class VitEngine:
                                        self.CP, T, st), 'l1_loss')
         return a['pred'], a['mloss']
 
-    def backward_masked(self, gscalar=None):
-        """loss + every gradient of the masked objective (the L1 kernel produces loss and dpred in one pass)"""
+    def backward_masked(self, gscalar=None, tiles_per_workgroup=0):
+        """loss + every gradient of the masked objective (the L1 kernel produces loss and dpred in one pass).
+        tiles_per_workgroup: as `backward`"""
+        self._tpw = int(tiles_per_workgroup)
+        try:
+            self._backward_masked(gscalar)
+        finally:
+            self._tpw = 0
+
+    def _backward_masked(self, gscalar):
         a, W, T = self.act, self.W, hip.code(self.dtype)
         l, st = lib(), stream()
         sv = self.saved
@@ -467,7 +485,7 @@ class VitEngine:
                                            self.CP, self.CP, T, st), 'l1_loss')
         self._colsum(a['dpred'], self.CP, G['pretrain.to_pixels.bias'], B * m, self.CP)
         self._wgrad(a['dpred'], a['rows'], 'pretrain.to_pixels.weight', self.CP, d, B * m)
-        hip.gemm(GEMM_NN, a['dpred'], W['pretrain.to_pixels.weight'], a['drows'], B * m, d, self.CP, self.CP, d, d)
+        self._gemm(GEMM_NN, a['dpred'], W['pretrain.to_pixels.weight'], a['drows'], B * m, d, self.CP, self.CP, d, d)
         dX = a['dxa']
         dX.zero_()
         check(l.ecgvit_scatter_rows(ptr(a['drows']), ptr(idx), ptr(dX), B, n, m, d, d, d, T, st), 'scatter_rows')
@@ -491,27 +509,38 @@ class VitEngine:
         d, h, dh, N = self.d, self.h, self.dh, self.T
         qkv, S = L['qkv'], L['probs']
         sq = (N * 3 * d, dh)
-        hip.gemm(GEMM_NT, qkv, qkv, S, N, N, dh, 3 * d, 3 * d, N, alpha=self.scale, batch=(B, h), strideA=sq, strideB=sq,
+        self._gemm(GEMM_NT, qkv, qkv, S, N, N, dh, 3 * d, 3 * d, N, alpha=self.scale, batch=(B, h), strideA=sq, strideB=sq,
                  strideC=(h * N * N, N * N), b_off=d)
         check(lib().ecgvit_softmax_rows(ptr(S), B * h * N, N, N, stream()), 'softmax_rows')
         Pd = S
         if ph > 0:
             Pd = self.act['pd']
             self._drop_apply_f32(S, Pd, B * h * N * N, ph, seed)
-        hip.gemm(GEMM_NN, Pd, qkv, L['attn'], N, dh, N, N, 3 * d, d, batch=(B, h), strideA=(h * N * N, N * N), strideB=sq,
+        self._gemm(GEMM_NN, Pd, qkv, L['attn'], N, dh, N, N, 3 * d, d, batch=(B, h), strideA=(h * N * N, N * N), strideB=sq,
                  strideC=(N * d, dh), b_off=2 * d)
 
     def _drop_apply_f32(self, src, dst, count, p, seed):
-        # element index = ((b*h + head)*N + q)*N + key: identical to the fused bf16 kernel's mask
+        # f32 parity path: the 16-bit pair hash of `ecgvit_dropout_apply` over element index ((b*h + head)*N + q)*N + key, exact p.
+        # NOT the fused bf16 kernels' mask (one 8-bit hash per four keys, p rounded to 1/256, pitch ceil(N/4)): the two paths drop
+        # different units, each consistently between its own forward and backward
         cnt8 = count // 8 * 8
         check(lib().ecgvit_dropout_apply(ptr(src), ptr(dst), cnt8, p, seed, hip.F32, stream()), 'dropout_apply')
         if cnt8 != count:
             raise ValueError('f32 attention dropout needs B*h*N*N to be a multiple of 8')
 
     # ---------------------------------------------------------------- backward
-    def backward(self, gscalar=None, gelem=None, gscale=1.0, glogits=None):
+    def backward(self, gscalar=None, gelem=None, gscale=1.0, glogits=None, tiles_per_workgroup=0):
         """Overwrites every gradient view in gflat. Upstream: `gscalar` (1,) for the mean loss, or `gelem` (B,K) for
-        reduction='none'; gscale folds the 1/(B*K) of the mean. `glogits` (B,K): extra upstream gradient on the logits."""
+        reduction='none'; gscale folds the 1/(B*K) of the mean. `glogits` (B,K): extra upstream gradient on the logits.
+        tiles_per_workgroup > 0: this pass's large A.B^T launches run as dispatcher-balanced chunks of about that many tiles (the
+        caller overlaps RCCL collectives with the pass, whose kernels hold CUs); the setting ends with the pass, exception or not."""
+        self._tpw = int(tiles_per_workgroup)
+        try:
+            self._backward(gscalar, gelem, gscale, glogits)
+        finally:
+            self._tpw = 0
+
+    def _backward(self, gscalar, gelem, gscale, glogits):
         a, W, T = self.act, self.W, hip.code(self.dtype)
         l, st = lib(), stream()
         sv = self.saved
@@ -630,16 +659,16 @@ class VitEngine:
             Pd = a['pd']
             self._drop_apply_f32(P, Pd, B * h * N * N, ph, seed)
         # dV = Pd^T dO
-        hip.gemm(GEMM_TN, Pd, dO, dqkv, N, dh, N, N, d, 3 * d, batch=(B, h), strideA=sp, strideB=so, strideC=sq, c_off=2 * d)
+        self._gemm(GEMM_TN, Pd, dO, dqkv, N, dh, N, N, d, 3 * d, batch=(B, h), strideA=sp, strideB=so, strideC=sq, c_off=2 * d)
         # dPd = dO V^T
-        hip.gemm(GEMM_NT, dO, qkv, dP, N, N, dh, d, 3 * d, N, batch=(B, h), strideA=so, strideB=sq, strideC=sp, b_off=2 * d)
+        self._gemm(GEMM_NT, dO, qkv, dP, N, N, dh, d, 3 * d, N, batch=(B, h), strideA=so, strideB=sq, strideC=sp, b_off=2 * d)
         if ph > 0:
             self._drop_apply_f32(dP, dP, B * h * N * N, ph, seed)
         # dS = P * (dP - rowsum(P dP)) * scale
         check(lib().ecgvit_softmax_bwd_rows(ptr(P), ptr(dP), B * h * N, N, N, self.scale, stream()), 'softmax_bwd_rows')
         # dQ = dS K ; dK = dS^T Q
-        hip.gemm(GEMM_NN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, b_off=d)
-        hip.gemm(GEMM_TN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, c_off=d)
+        self._gemm(GEMM_NN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, b_off=d)
+        self._gemm(GEMM_TN, dP, qkv, dqkv, N, dh, N, N, 3 * d, 3 * d, batch=(B, h), strideA=sp, strideB=sq, strideC=sq, c_off=d)
 
     # ---------------------------------------------------------------- per-layer attention probabilities (f3)
     def attention_probs(self, layer):

@@ -68,17 +68,20 @@ class DeviceFeeder:
     Double-buffered: while the step consumes batch i, a worker thread gathers batch i+1 from the (memory-mapped) store into pinned
     memory (float64 -> float32 as the reference's `__getitem__` does) and queues its H2D copy on a side stream; the consumer's stream
     waits on the copy's event only.  `shuffle` permutes with `torch.randperm` per epoch (seeded); `rank/world` take a contiguous,
-    equally long shard of every epoch's order (wrapped around when n is not a multiple of the world size).  On a CPU-only host (tests) it degrades to synchronous host tensors.
+    equally long shard of every epoch's order (wrapped around when n is not a multiple of the world size: `pad=True`, what the
+    collective train step needs).  `pad=False` (EVALUATION) deals the exact records instead -- the last ranks' shards are up to
+    world-1 records shorter and nothing is counted twice; `HipEvaluator(gather=True)` all-gathers unequal shards by their true sizes.
+    On a CPU-only host (tests) it degrades to synchronous host tensors.
     """
 
     def __init__(self, records, idxs, labels_multi_hot, batch_size, shuffle=False, seed=77, device=None, rank=0, world=1,
-                 drop_last=False):
+                 drop_last=False, pad=True):
         self.rec = open_records(records)
         self.idxs = np.asarray(idxs, dtype=np.int64)
         self.labels = np.ascontiguousarray(labels_multi_hot, dtype=np.float32)
         assert len(self.idxs) == len(self.labels)
         self.bsz, self.shuffle, self.seed, self.drop_last = int(batch_size), shuffle, seed, drop_last
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.pad = rank, world, bool(pad)
         self.device = torch.device(device) if device is not None else torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.on_gpu = self.device.type == 'cuda'
         self.epoch = 0
@@ -86,6 +89,8 @@ class DeviceFeeder:
 
     def __len__(self):
         n = self._shard_len()
+        if not self.pad:   # exact shard of this rank (evaluation): may be shorter than the others', or empty
+            n = max(0, min(n, len(self.idxs) - self.rank * n))
         return n // self.bsz if self.drop_last else (n + self.bsz - 1) // self.bsz
 
     def _shard_len(self):
@@ -103,7 +108,7 @@ class DeviceFeeder:
         else:
             perm = np.arange(n)
         per = self._shard_len()
-        if per * self.world > n:
+        if self.pad and per * self.world > n:
             perm = np.concatenate([perm, perm[:per * self.world - n]])
         return perm[self.rank * per:(self.rank + 1) * per]
 

@@ -12,16 +12,14 @@ from ctypes import c_int, c_int32, c_int64, c_uint64, c_float, c_void_p, c_char_
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('ECGVIT_HIP_LIB') or os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # env: A/B another build of the same ABI
+LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # the ONE library a drop-in user loads; no environment variable changes it
 
 F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT = 128, 256, 512
 
-# default of `ecgvit_gemm_desc.tiles_per_workgroup` for every GEMM issued through `gemm()`: 0 = persistent static shares (the launch
-# owns the GPU); HipTrainStep sets it to 2 while gradient all-reduce buckets overlap the backward pass (RCCL kernels hold CUs)
-GEMM_TILES_PER_WORKGROUP = 0
+KERNEL_NONE, KERNEL_GEMM_F32, KERNEL_GEMM_BF16, KERNEL_GEMM_NT, KERNEL_GEMM_WGRAD = 0, 1, 2, 3, 4
 
 _ERR = {1: 'ECGVIT_EINVAL (unsupported shape / argument)', 2: 'ECGVIT_ELAUNCH (HIP launch failure)'}
 
@@ -52,6 +50,7 @@ SIGNATURES = {
     'ecgvit_abi_version': (c_int, []),
     'ecgvit_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'ecgvit_gemm_workspace': (c_int64, [POINTER(GemmDesc)]),
+    'ecgvit_gemm_kernel': (c_int, [POINTER(GemmDesc)]),
     'ecgvit_fp8_amax': (c_int, [_P, _P, _I, _L, _P, _P]),
     'ecgvit_fp8_quantize': (c_int, [_P, _P, _P, _I, _L, _I, _P, _P, _P]),
     'ecgvit_fp8_scale_update': (c_int, [_P, _P, _I, _P, _I, _P]),
@@ -95,6 +94,17 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def use_library(path):
+    """Measurement tools only (tools/*, bench.py --hip-lib): load ANOTHER build of the same ABI (the stamped diagnostic build, an A/B
+    candidate) instead of the shipped library.  Explicit call, before the first kernel call of the process -- never ambient state."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError('use_library() must come before the first ecgvit call of the process')
+    if not os.path.exists(path):
+        raise HipLibraryMissing(f'{path} not found')
+    LIB_PATH = os.path.abspath(path)
 
 
 def lib():
@@ -145,7 +155,7 @@ def _need_cuda(*ts):
 # ------------------------------------------------------------------------------------------------
 def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None, residual=None, ldr=0, aux=None, ldaux=0,
               alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
-              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=None, fp8_format=None, scale_a=None, scale_b=None, q8_out=None, ldq8=0, q8_scale=None,
+              a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=0, fp8_format=None, scale_a=None, scale_b=None, q8_out=None, ldq8=0, q8_scale=None,
               q8_amax=None, q8_format=0):
     """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
     _need_cuda(A, B, C)
@@ -160,7 +170,7 @@ def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None,
     d.bias, d.residual, d.ldr, d.aux, d.ldaux = ptr(bias), ptr(residual), ldr, ptr(aux), ldaux
     d.alpha, d.dropout_p, d.dropout_seed = alpha, dropout_p, seed
     d.colsum_out = ptr(colsum_out)
-    d.tiles_per_workgroup = GEMM_TILES_PER_WORKGROUP if tiles_per_workgroup is None else tiles_per_workgroup
+    d.tiles_per_workgroup = tiles_per_workgroup   # 0 = persistent static shares; the engine passes 2 while RCCL buckets overlap its backward
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     return d
@@ -170,6 +180,12 @@ def gemm(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw):
     """C = epilogue(alpha * op(A) . op(B)); keyword arguments as `gemm_desc`."""
     d = gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw)
     check(lib().ecgvit_gemm(byref(d), stream()), 'ecgvit_gemm')
+
+
+def gemm_kernel(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw):
+    """KERNEL_* id of the kernel family `gemm()` would launch for these arguments (the library's own dispatch, nothing launched)"""
+    d = gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, **kw)
+    return lib().ecgvit_gemm_kernel(byref(d))
 
 
 def gemm_workspace_bytes(layout, dtype, M, N, K):

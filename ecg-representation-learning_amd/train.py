@@ -152,10 +152,11 @@ class HipTrainStep:
             self._xchg.begin(model._gflat)
             eng.on_grads_ready = self._xchg.bucket_ready if self.overlap else None
             # RCCL kernels will hold CUs while the rest of the backward runs: hand the GEMM tiles out in small chunks instead of
-            # static per-CU shares (tools/contention.py: 8 held CUs cost a static launch +52 %, a chunked one +9 %)
-            hip.GEMM_TILES_PER_WORKGROUP = 2 if self.overlap else 0
-        else:
-            eng.on_grads_ready = None
+            # static per-CU shares (tools/contention.py: 8 held CUs cost a static launch +52 %, a chunked one +9 %) -- an argument of
+            # THIS backward pass, not process state
+            return 2 if self.overlap else 0
+        eng.on_grads_ready = None
+        return 0
 
     def step_masked(self, sample_values, mask_idx):
         """the same fused step for the masked pre-train objective; `self.model` must be a MaskedEcgVit"""
@@ -171,8 +172,11 @@ class HipTrainStep:
         idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
         pred, loss = eng.forward_masked(x, idx, training=True, seed=seed)
         model._fwd_id += 1
-        self._arm_overlap(model)
-        eng.backward_masked()
+        tpw = self._arm_overlap(model)
+        try:
+            eng.backward_masked(tiles_per_workgroup=tpw)
+        finally:
+            eng.on_grads_ready = None
         loss, pred = loss.clone(), pred.clone()   # the engine reuses its buffers next step: hand out copies
         self._update(model)
         self.last_loss = loss
@@ -182,7 +186,6 @@ class HipTrainStep:
         gflat = model._gflat
         if self.collectives:
             self._xchg.finish()
-            hip.GEMM_TILES_PER_WORKGROUP = 0
         l = hip.lib()
         st = hip.stream()
         hip.check(l.ecgvit_sumsq(gflat.data_ptr(), gflat.numel(), self.sumsq.data_ptr(), self.ws.data_ptr(), st), 'sumsq')
@@ -217,8 +220,11 @@ class HipTrainStep:
         logits, _, loss_mean = eng.forward(x, y, w, training=True, seed=seed, want_mean=True)
         model._fwd_id += 1
         B, K = x.shape[0], eng.K
-        self._arm_overlap(model)
-        eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K))
+        tpw = self._arm_overlap(model)
+        try:
+            eng.backward(gscalar=self._one(x.device), gscale=1.0 / (B * K), tiles_per_workgroup=tpw)
+        finally:
+            eng.on_grads_ready = None
         loss_mean, logits = loss_mean.clone(), logits.clone()   # the engine reuses its buffers next step: hand out copies
         self._update(model)
         self.last_loss = loss_mean

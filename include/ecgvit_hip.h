@@ -90,18 +90,26 @@ typedef struct ecgvit_gemm_desc {
     void *workspace;      /* optional split-K slabs (bf16 TN); see ecgvit_gemm_workspace */
     int64_t workspace_bytes;
     float *colsum_out;    /* [N] f32, with ECGVIT_EPI_COLSUM */
-    int32_t tiles_per_workgroup; /* large products only. 0: persistent launch, one workgroup per CU walks a static share of the
-                             output tiles (fastest when the launch owns the GPU). k > 0: ceil(tiles / k) workgroups of about k tiles
-                             each, handed out by the hardware dispatcher as CUs free up -- use it when other kernels (RCCL
-                             collectives overlapped with the backward pass) hold CUs, where a static share would leave the
-                             workgroups that start late a full share behind (large weight-gradient products then cut three times as many K-slices).
-                             A.B^T results are identical either way; the weight-gradient sum order follows the slice count. */
+    int32_t tiles_per_workgroup; /* large A.B^T products (gemm_nt launches) only. 0: persistent launch, one workgroup per CU walks a
+                             static share of the output tiles (fastest when the launch owns the GPU). k > 0: ceil(tiles / k) workgroups
+                             of about k tiles each, handed out by the hardware dispatcher as CUs free up -- use it when other kernels
+                             (RCCL collectives overlapped with the backward pass) hold CUs, where a static share would leave the
+                             workgroups that start late a full share behind. Results are bit-identical either way. Weight-gradient
+                             (ECGVIT_GEMM_TN) products ignore the field: their K-slicing and sum order never depend on it. */
     void *q8_out; int64_t ldq8; const float *q8_scale; float *q8_amax; int32_t q8_format; /* with ECGVIT_EPI_QUANT_OUT */
     const float *scale_a, *scale_b; /* optional device scalars multiplied into alpha: the per-tensor scales of 8-bit operands
                              (x ~= q * scale), read by the kernel -- no host round trip between the quantise pass and the product */
 } ecgvit_gemm_desc;
 
 int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
+/* which kernel family ecgvit_gemm would launch for this descriptor (nothing is launched, pointers are not dereferenced but must be
+ * the real ones: alignment decides eligibility).  Lets a profiler attribute a call to a kernel symbol without restating the dispatch. */
+#define ECGVIT_KERNEL_NONE 0        /* the call would return ECGVIT_EINVAL                                   */
+#define ECGVIT_KERNEL_GEMM_F32 1    /* gemm_f32_kernel: exact-f32 MFMA parity path                           */
+#define ECGVIT_KERNEL_GEMM_BF16 2   /* gemm_bf16_kernel: small / ragged bf16 products                        */
+#define ECGVIT_KERNEL_GEMM_NT 3     /* gemm_nt_kernel: persistent 256x256x64 A.B^T (bf16 or 8-bit operands)  */
+#define ECGVIT_KERNEL_GEMM_WGRAD 4  /* gemm_wgrad_kernel: streaming split-K weight gradients                 */
+int ecgvit_gemm_kernel(const ecgvit_gemm_desc *d);
 /* bytes of workspace with which the call would use its preferred split-K factor (0 = none needed) */
 int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d);
 
@@ -175,7 +183,10 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
  * Multi-head self-attention core, fused (bf16 path).  replaces vit_pytorch Attention.forward between
  * to_qkv and to_out: split heads, dots = q k^T * dh^-0.5, softmax, (dropout), attn v, merge heads.
  * qkv: [B*N, 3*h*dh] (columns [q | k | v], head-major inside each) ; out: [B*N, h*dh] ; lse: [B,h,N] f32.
- * bf16 path requires dh == 64; forward N <= 512 (online softmax over 32-key tiles), backward N <= 256.
+ * bf16 path requires dh == 64 and N <= 512 (online softmax over 32-key tiles; the backward takes 256 < N <= 512 as two key windows).
+ * Probability dropout of the fused kernels: one 8-bit hash per 4 consecutive keys, so the probability APPLIED is
+ * round(256 p) / 256 (p = 0.1 -> 26/256 = 0.1016), kept values rescaled by the exact 256 / (256 - round(256 p)); 0 < p < 1/512 cannot be
+ * represented and is rejected (ECGVIT_EINVAL) rather than silently rounded to no dropout.
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale,
                          float dropout_p, uint64_t seed, int dtype, void *stream);

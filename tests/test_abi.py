@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_abi():
     l = E.hip.lib()
-    assert l.ecgvit_abi_version() == 2
+    assert l.ecgvit_abi_version() == 3
     assert b'gfx950' in l.ecgvit_version()
 
 

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N > 1 path's logic -- contiguous equal shards, one SUM all-reduce over the flat gradient
+"""CPU, world_size 2 / 4 / 8, gloo: the N > 1 path's logic -- contiguous equal shards, one SUM all-reduce over the flat gradient
 buffer, 1/world folded into the update, clip on the REDUCED gradient -- reproduces the single-process full-batch step.
 The per-rank compute here is the CPU oracle (the HIP kernels need a GPU); what is under test is ecg_..._amd.ddp + the
 flat layout, which are device-agnostic and are exactly what HipTrainStep calls on the GPU."""
@@ -30,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     import ecg_representation_learning_amd as E
     from ecg_representation_learning_amd.engine import ParamLayout
     from oracle import vit_oracle as O
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
     cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
     torch.manual_seed(1234 + rank)                      # deliberately different init per rank ...
     model = O.OracleEcgVit(config=cfg).train()
@@ -40,7 +40,7 @@ def _worker(rank, world, port, out_dir):
         layout.view(pflat, n).copy_(p.data)
         p.data = layout.view(pflat, n)
     E.ddp.broadcast_flat_(pflat, src=0)                 # ... made identical by one broadcast of the flat buffer
-    G = 8
+    G = 8 if world <= 4 else 16                        # global batch: 4 / 2 / 2 records per rank
     x, y = O.synthetic_batch(G, length=400, seed=77)    # the GLOBAL batch, identical on every rank
     lo, hi = E.ddp.shard_range(G, rank, world)
     out = model(sample_values=x[lo:hi], labels=y[lo:hi])
@@ -71,29 +71,50 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
-    world = 2
+# bf16 on the wire: each rank's bucket is rounded to 8 significant bits and the ring sums in bf16 -> relative error of the reduced
+# gradient ~2^-9 * sqrt(world).  Bounds per world size, and the bf16 path's own per-tensor gradient tolerance (cosine >= 0.98,
+# tests/test_gpu_configs.py) held against the f32 exchange: measured here (gloo ring) 2.3e-3 / 2.7e-3 / 3.1e-3 at world 2 / 4 / 8, worst cosine 0.99999
+# for every parameter tensor -- bf16 buckets stay a supported wire dtype at 8 ranks (f32 remains the default).
+BF16_WIRE_REL = {2: 8e-3, 4: 1.0e-2, 8: 1.4e-2}
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_gradient_allreduce_equals_full_batch(tmp_path, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in range(world))
-    assert torch.equal(r0['p'], r1['p'])                       # broadcast made the replicas identical
-    assert torch.allclose(r0['g'], r1['g'], rtol=0, atol=0)    # every rank holds the same reduced, clipped gradient
-    assert (r0['seed'], r1['seed']) == (77, 78)
-    # GradExchange: the f32 forms equal the plain all-reduce bit for bit; bf16 on the wire stays within bf16 rounding of it
-    for tag in ('f32_overlap', 'f32_single'):
-        assert torch.equal(r0['xchg'][tag], r0['gavg']) and torch.equal(r1['xchg'][tag], r0['gavg'])
-    for tag in ('bf16_overlap', 'bf16_single'):
-        assert torch.equal(r0['xchg'][tag], r1['xchg'][tag])
-        rel = float((r0['xchg'][tag] - r0['gavg']).norm() / r0['gavg'].norm())
-        assert 0 < rel < 8e-3, rel          # tolerance: 2 ranks x bf16 (8 significant bits) contributions, bf16 sum
-    # single-process full-batch reference
+    rs = [torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in range(world)]
+    r0, r1 = rs[0], rs[1]
+    G = 8 if world <= 4 else 16
+    for r in rs[1:]:
+        assert torch.equal(r0['p'], r['p'])                       # broadcast made the replicas identical
+        assert torch.equal(r0['g'], r['g'])                       # every rank holds the same reduced, clipped gradient
+    assert [r['seed'] for r in rs] == [77 + i for i in range(world)]
     from ecg_representation_learning_amd.engine import ParamLayout
     from oracle import vit_oracle as O
     cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
     torch.manual_seed(1234)
     model = O.OracleEcgVit(config=cfg).train()
     layout = ParamLayout([(n, tuple(p.shape)) for n, p in model.named_parameters()])
-    x, y = O.synthetic_batch(8, length=400, seed=77)
+    # GradExchange: the f32 forms equal the plain all-reduce bit for bit; bf16 on the wire stays within bf16 rounding of it
+    # (world 2: a + b has one order; beyond that a ring's sum order depends on how the buffer is cut into buckets -> f32 rounding)
+    for tag in ('f32_overlap', 'f32_single'):
+        for r in rs:
+            assert torch.equal(r['xchg'][tag], r0['xchg'][tag])
+            if world == 2:
+                assert torch.equal(r['xchg'][tag], r0['gavg'])
+            else:
+                assert float((r['xchg'][tag] - r0['gavg']).norm() / r0['gavg'].norm()) < 1e-6
+    for tag in ('bf16_overlap', 'bf16_single'):
+        for r in rs[1:]:
+            assert torch.equal(r0['xchg'][tag], r['xchg'][tag])
+        rel = float((r0['xchg'][tag] - r0['gavg']).norm() / r0['gavg'].norm())
+        assert 0 < rel < BF16_WIRE_REL[world], (world, rel)
+        worst = min(float(torch.nn.functional.cosine_similarity(layout.view(r0['xchg'][tag], n).flatten(), layout.view(r0['gavg'], n).flatten(), dim=0))
+                    for n in layout.entries if float(layout.view(r0['gavg'], n).norm()) > 0)
+        print(f'world {world} {tag}: reduced-gradient rel error {rel:.2e}, worst per-tensor cosine {worst:.6f}')
+        assert worst >= 0.98, (world, tag, worst)
+    # single-process full-batch reference
+    x, y = O.synthetic_batch(G, length=400, seed=77)
     out = model(sample_values=x, labels=y)
     out.loss.backward()
     tn = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
@@ -102,7 +123,7 @@ def test_two_rank_gradient_allreduce_equals_full_batch(tmp_path):
         layout.view(g, n).copy_(p.grad)
     assert abs(float(r0['norm']) - float(tn)) / float(tn) < 1e-5
     assert float((r0['g'] - g).norm() / g.norm()) < 1e-5
-    assert abs(float(out.loss) - 0.5 * (float(r0['loss']) + float(r1['loss']))) < 1e-6   # mean of shard means
+    assert abs(float(out.loss.detach()) - sum(float(r['loss']) for r in rs) / world) < 1e-6   # mean of shard means
 
 
 def test_shard_range_contract():

@@ -85,3 +85,64 @@ def test_grad_exchange_streams_on_gpu(nccl_group):
         ex.begin(torch.zeros(n, device='cuda'))
         ex.bucket_ready('b0')
         ex.finish()                                # seven buckets never reported
+
+
+def test_failed_overlapped_step_leaves_no_launch_geometry_behind(nccl_group, monkeypatch):
+    """`tiles_per_workgroup` is an argument of ONE backward pass (engine.backward(..., tiles_per_workgroup=)), not process state: a
+    step that dies inside the overlapped backward -- here the gradient exchange never hears of a bucket and `finish()` raises, after an
+    exception thrown from inside the backward itself -- must leave the next plain step (and any other model in the process) on
+    persistent launches."""
+    from ecg_representation_learning_amd import hip
+    seen = []
+    real = hip.gemm
+
+    def spy(layout, *a, **k):
+        seen.append(k.get('tiles_per_workgroup', 0))
+        return real(layout, *a, **k)
+    monkeypatch.setattr(hip, 'gemm', spy)
+    assert not hasattr(hip, 'GEMM_TILES_PER_WORKGROUP')          # the process-wide knob is gone
+    m = _model()
+    x, y = E.workload.synthetic_batch(24, length=5000, seed=3)
+    x, y = x.cuda(), y.cuda()
+    st = E.HipTrainStep(m, dict(n_step=20, warmup_ratio=0.0), single_rank_collectives=True, overlap_allreduce=True)
+    st.step(x, y)
+    assert 2 in seen and m._engine()._tpw == 0                   # the overlapped backward ran chunked; the setting ended with the pass
+    eng = m._engine()
+    boom = RuntimeError('injected failure inside the backward pass')
+    real_ready = eng._ready
+
+    def failing_ready(tag):
+        if tag == 'layer0':
+            raise boom
+        real_ready(tag)
+    eng._ready = failing_ready
+    with pytest.raises(RuntimeError, match='injected failure'):
+        st.step(x, y)
+    eng._ready = real_ready
+    torch.cuda.synchronize()
+    assert eng._tpw == 0 and eng.on_grads_ready is None
+    # the next PLAIN step of the same process: persistent launches only
+    seen.clear()
+    plain = E.HipTrainStep(_model(seed=6), dict(n_step=20, warmup_ratio=0.0))
+    plain.step(x, y)
+    plain.finish()
+    torch.cuda.synchronize()
+    assert seen and set(seen) == {0}
+
+
+def test_bench_self_launcher_single_rank_collectives():
+    """`python bench.py --gpus 1 --single-rank-collectives` goes through the SAME launcher code `--gpus 8` would use without torchrun:
+    the parent starts the rank processes before touching the GPU, relays rank 0's JSON line, and reports the RCCL group size."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--single-rank-collectives', '--steps', '3', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-masked', '--batch', '64'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['rccl_ranks'] == 1 and out['n_gpus'] == 1 and len(out['rank_ms_per_step']) == 1
+    assert out['config']['parallelism'] == 'dp1+single-rank-collectives' and out['value'] > 0

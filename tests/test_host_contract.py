@@ -166,6 +166,14 @@ def test_ptbxl_splits_multi_hot_and_feeder_order(tmp_path):
     odd = idx[:len(idx) - 1 + (len(idx) % 2)]           # force an odd record count: n = 2k + 1 -> k + 1 records on both ranks
     fo = [E.DeviceFeeder(rec, odd, mh[odd], 4, shuffle=False, device='cpu', rank=r, world=2) for r in range(2)]
     assert len(odd) % 2 == 1 and len(fo[0]) == len(fo[1]) == ((len(odd) + 1) // 2 + 3) // 4
+    # evaluation shards (pad=False): the exact records, nothing counted twice -- world 3 over an odd count leaves the last rank short
+    fe = [E.DeviceFeeder(rec, odd, mh[odd], 4, shuffle=False, device='cpu', rank=r, world=3, pad=False) for r in range(3)]
+    ev = [list(f) for f in fe]
+    assert [len(b) for b in ev] == [len(f) for f in fe]
+    allx = torch.cat([torch.cat([b['sample_values'] for b in bs]) for bs in ev if bs])
+    assert torch.equal(allx, torch.from_numpy(rec[odd].astype(np.float32)))   # every record exactly once, in order
+    per = (len(odd) + 2) // 3
+    assert [sum(b['labels'].shape[0] for b in bs) for bs in ev] == [min(per, max(0, len(odd) - r * per)) for r in range(3)]
     try:
         import h5py  # noqa: F401
     except ImportError:

@@ -1,3 +1,4 @@
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dp_prof; rm -rf $O; mkdir -p $O
 A="--steps 3 --warmup 1 --no-cpu-baseline --no-probe --no-masked"

@@ -16,9 +16,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault('ECGVIT_HIP_LIB', os.path.join(ROOT, 'ecg-representation-learning_amd', 'libecgvit_hip_tools.so'))
 import ecg_representation_learning_amd as E  # noqa: E402,F401
 from ecg_representation_learning_amd import hip  # noqa: E402
+hip.use_library(os.path.join(ROOT, 'ecg-representation-learning_amd', 'csrc', 'build', 'libecgvit_hip_tools.so'))   # explicit: the diagnostic build, never the shipped library
 from ecg_representation_learning_amd.hip import (EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM,  # noqa: E402
                                                   EPI_GELU_GRAD_AUX, EPI_MUL_AUX, GEMM_NT)
 

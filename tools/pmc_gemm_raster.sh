@@ -2,6 +2,7 @@
 # fabric traffic and L2 hit rate of gemm_nt_kernel on one Linear shape for several column-group sizes (tools build)
 # usage: bash tools/pmc_gemm_raster.sh "fwd qkv" "0,1,3,5"
 ONLY=${1:-fwd qkv}; GROUPS_=${2:-0,3}
+: "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_raster; rm -rf $O; mkdir -p $O
 for C in FETCH_SIZE "TCC_HIT_sum TCC_MISS_sum"; do

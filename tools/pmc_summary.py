@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,7 +30,8 @@ def family(n):
 
 
 def main():
-    out_dir, obj = sys.argv[1], sys.argv[2]
+    out_dir, tag, bench_args = sys.argv[1], sys.argv[2], sys.argv[3:]
+    import bench
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(out_dir, '*', '*', '*counter_collection.csv'))):
         for r in csv.DictReader(open(f)):
@@ -37,11 +39,21 @@ def main():
             if k:
                 agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
     dur = collections.defaultdict(list)
-    for f in sorted(glob.glob(os.path.join(out_dir, 'trace', '*', '*kernel_trace.csv'))):
-        for r in csv.DictReader(open(f)):
-            k = family(r['Kernel_Name'])
-            if k:
-                dur[k].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-3)
+    traces = sorted(glob.glob(os.path.join(out_dir, 'trace', '*', '*kernel_trace.csv')))
+    assert len(traces) == 1, f'expected exactly one trace pass under {out_dir}/trace, found {traces}'
+    for r in csv.DictReader(open(traces[0])):
+        k = family(r['Kernel_Name'])
+        if k:
+            dur[k].append((float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-3)
+    # the --stats table of THE SAME trace pass travels with the summary (tools/check_profiles.py recomputes the averages from it)
+    stats = traces[0].replace('kernel_trace.csv', 'kernel_stats.csv')
+    shutil.copyfile(stats, os.path.join(out_dir, 'kernel_stats.csv'))
+    stat_fam = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(stats)):
+        k = family(r['Name'])
+        if k:
+            stat_fam[k][0] += int(r['Calls'])
+            stat_fam[k][1] += float(r['TotalDurationNs'])
     kernels = {}
     for k in sorted(set(agg) | set(dur)):
         o = {c: sum(v) / len(v) for c, v in agg[k].items()}
@@ -49,6 +61,8 @@ def main():
             o['launches_per_run'] = len(dur[k])
             o['avg_us'] = sum(dur[k]) / len(dur[k])
             o['total_ms'] = sum(dur[k]) * 1e-3
+        if k in stat_fam:
+            o['stats_calls'], o['stats_total_ns'] = stat_fam[k]
         if 'FETCH_SIZE' in o and 'WRITE_SIZE' in o:
             o['hbm_bytes_per_launch'] = (2.0 * o['FETCH_SIZE'] + o['WRITE_SIZE']) * 1024.0
             if 'avg_us' in o:
@@ -57,18 +71,22 @@ def main():
             o['l2_hit_rate'] = o['TCC_HIT_sum'] / max(1.0, o['TCC_HIT_sum'] + o['TCC_MISS_sum'])
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in o and o.get('SQ_BUSY_CYCLES'):
             o['mfma_busy_over_sq_busy'] = o['SQ_VALU_MFMA_BUSY_CYCLES'] / o['SQ_BUSY_CYCLES']
+        if 'SQ_VALU_MFMA_BUSY_CYCLES' in o and o.get('GRBM_GUI_ACTIVE'):
+            # MFMA-busy share of the SIMD cycles: busy cycles summed over 1024 SIMDs / (GRBM_GUI_ACTIVE summed over 8 XCDs / 8)
+            o['mfma_busy_frac'] = o['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024.0 / (o['GRBM_GUI_ACTIVE'] / 8.0)
         kernels[k] = o
-    import bench
-    res = dict(objective=obj, command=f'bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-masked --objective {obj} (EcgVit-base bf16, 512 x 12 x 5000)',
-               kernel_source_sha16=bench.kernel_source_hash(),
-               notes='per-launch averages over all launches of a family in the run (3 steps incl. warm-up); FETCH_SIZE/WRITE_SIZE in KiB; '
+    wargs = bench.parse_args(bench_args)
+    res = dict(tag=tag, workload_key=bench.workload_key(wargs), command='bench.py ' + ' '.join(bench_args),
+               kernel_source_sha16=bench.kernel_source_hash(), steps_in_run=wargs.steps + wargs.warmup,
+               stats_csv='kernel_stats.csv (the --stats table of the same trace pass; stats_calls / stats_total_ns per family are read from it)',
+               notes='per-launch averages over all launches of a family in the run (steps + warm-up); FETCH_SIZE/WRITE_SIZE in KiB; '
                      'hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE reports half of wide streaming reads); '
                      'SQ_* summed over all SEs/XCDs; profiled passes run 2-3 % slower than unprofiled ones (DVFS), durations come from the trace-only pass',
                kernels=kernels)
     with open(os.path.join(out_dir, 'summary.json'), 'w') as f:
         json.dump(res, f, indent=1)
     for k, o in kernels.items():
-        print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in o.items() if a in ('avg_us', 'launches_per_run', 'hbm_bytes_per_launch', 'hbm_GBps', 'l2_hit_rate', 'mfma_busy_over_sq_busy', 'total_ms')})
+        print(k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in o.items() if a in ('avg_us', 'launches_per_run', 'hbm_bytes_per_launch', 'hbm_GBps', 'l2_hit_rate', 'mfma_busy_over_sq_busy', 'mfma_busy_frac', 'total_ms')})
 
 
 if __name__ == '__main__':
