@@ -156,19 +156,52 @@ static inline uint32_t dropout_threshold(float p) {
 }
 
 // ---- bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16's 2^-8), one exp + one rcp;
-//      GELU' reuses the same exponential (erf(x/sqrt2) is built on e^{-x^2/2} = sqrt(2 pi) * pdf) -----------------
-__device__ __forceinline__ void gelu_fast_parts(float x, float &cdf, float &pdf) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE division
-    const float ex = __expf(-z * z);
+//      GELU' reuses the same exponential (erf(x/sqrt2) is built on e^{-x^2/2} = sqrt(2 pi) * pdf).
+//      ONE formulation for every kernel (the 128^2 GEMM, the persistent GEMM, the split-K reducer): the same record must produce the
+//      same bits whichever kernel its batch size selects (eval logits are batch-slice invariant: tests/test_gpu_model.py).
+//      cdf_k = k * Phi(x), pdf_k = k * phi(x) for a wave-uniform k >= 0 passed as hk = k/2, ck = k/sqrt(2 pi): the FFN-up epilogue
+//      folds the dropout rescale 1/(1-p) in here; everything else passes k = 1.  |x| is a source modifier and the exponential is
+//      taken as 2^(-u^2), u = |x| sqrt(log2(e)/2): 14 VALU instructions for both parts.
+#define ECGVIT_GELU_HK1 0.5f
+#define ECGVIT_GELU_CK1 0.39894228040143267794f
+__device__ __forceinline__ void gelu_fast_parts_scaled(float x, float hk, float ck, float &cdf, float &pdf) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));   // v_rcp_f32 (1 ulp)
+    const float u = ax * 0.84932180028801904272f;
+    const float ex = __builtin_amdgcn_exp2f(-u * u);   // = e^{-x^2/2}
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * ex;
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    pdf = 0.39894228040143267794f * ex;
+    const float s = copysignf(fmaf(-poly, ex, 1.0f), x);   // erf(x / sqrt 2)
+    cdf = fmaf(hk, s, hk);
+    pdf = ck * ex;
 }
+__device__ __forceinline__ void gelu_fast_parts(float x, float &cdf, float &pdf) { gelu_fast_parts_scaled(x, ECGVIT_GELU_HK1, ECGVIT_GELU_CK1, cdf, pdf); }
 __device__ __forceinline__ float gelu_fast(float x) { float c, p; gelu_fast_parts(x, c, p); return x * c; }
 __device__ __forceinline__ void gelu_fast_both(float x, float &y, float &dy) { float c, p; gelu_fast_parts(x, c, p); y = x * c; dy = fmaf(x, p, c); }
-__device__ __forceinline__ float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return c + x * p; }
+__device__ __forceinline__ float gelu_fast_grad(float x) { float c, p; gelu_fast_parts(x, c, p); return fmaf(x, p, c); }
+// y = k * gelu(x), dy = k * gelu'(x)
+__device__ __forceinline__ void gelu_fast_both_scaled(float x, float hk, float ck, float &y, float &dy) {
+    float c, p;
+    gelu_fast_parts_scaled(x, hk, ck, c, p);
+    y = x * c;
+    dy = fmaf(x, p, c);
+}
+
+// Drop mask of the pair of consecutive elements hashed to h, as a dword: 0xFFFF in the half of a DROPPED element (half < thresh,
+// unsigned), 0 in the half of a kept one -- packed 16-bit arithmetic on the two halves at once: h ^ 0x80008000 maps the unsigned
+// order onto the signed one, a saturating signed subtract of the (equally flipped) threshold keeps the sign of the difference, an
+// arithmetic shift spreads it.  The same keep set as dropout_pair(), three instructions per PAIR, applied to packed bf16 results with
+// one AND-NOT each (the rescale 1/(1-p) is folded into the values beforehand).  tflip2 = ((thresh ^ 0x8000) & 0xFFFF) * 0x10001.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dropmask_of_pair(uint32_t h, uint32_t tflip2) {
+    const s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, h ^ 0x80008000u), __builtin_bit_cast(s16x2_t, tflip2));
+    return __builtin_bit_cast(uint32_t, d >> (s16x2_t){15, 15});
+}
+// drop masks of 8 consecutive elements starting at an EVEN index: the pairs of dropout_maskN<8>
+__device__ __forceinline__ void dropmask8(uint64_t seed, uint32_t idx0, uint32_t tflip2, uint32_t (&m)[4]) {
+    const uint32_t base = pair_base(seed, idx0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = dropmask_of_pair(pair_finish(base + (uint32_t)k * ECGVIT_WEYL), tflip2);
+}
 
 // ---- epilogue parameters shared by the f32 and bf16 GEMMs -------------------------------------
 struct EpiParams {

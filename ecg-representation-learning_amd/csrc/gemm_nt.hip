@@ -96,6 +96,41 @@ __device__ __forceinline__ u32x4 nt_permute(const u32x4 &x, int addr) {
     return y;
 }
 
+// what follows the store of one run: column sums and the 8-bit copy, both of the values AS STORED (`out` = the packed bf16 run in the
+// accumulator layout)
+template <int FL>
+__device__ __forceinline__ void nt_epi8_tail(const u32x4 &out, bool ok, bool okm, uint32_t mm, uint32_t ncm, const NtBufs &bf, float *cs8, float &qmax,
+                                             int rt_flags = 0) {
+    struct { int flags; } e{rt_flags};
+    if (NT_HAS(ECGVIT_EPI_COLSUM)) {   // of the values as stored; masked lanes add nothing
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { cs8[2 * k] += ok ? bf16_lo(out[k]) : 0.f; cs8[2 * k + 1] += ok ? bf16_hi(out[k]) : 0.f; }
+    }
+    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // the 8-bit copy of the values as stored (what a separate quantise pass would read back)
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] = bf16_lo(out[k]); f[2 * k + 1] = bf16_hi(out[k]); }
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) qmax = fmaxf(qmax, fabsf(f[k]));
+        }
+        const float mx = bf.q8_bf8 ? 57344.f : 448.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = __builtin_amdgcn_fmed3f(f[k] * bf.q8_inv, -mx, mx);
+        int w0 = 0, w1 = 0;
+        if (bf.q8_bf8) {
+            w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+        } else {
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+        }
+        u32x2 q;
+        q[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w0); q[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w1);
+        __builtin_amdgcn_raw_buffer_store_b64(q, bf.q8, okm ? mm * (uint32_t)bf.ldq + ncm : NT_OOB, 0, 0);
+    }
+}
+
 template <typename TO, int FL>
 __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, uint32_t mm, uint32_t ncm, bool okm,
                                         const NtBufs &bf, const EpiParams &e, const u32x4 &res, const u32x4 &auxin, float *cs8, float &qmax) {
@@ -106,6 +141,32 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
     if (NT_HAS(ECGVIT_EPI_BIAS)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+    }
+    // FFN-up forward (bias + erf-GELU + saved GELU' x mask [+ dropout]): the launch whose epilogue is VALU-bound.  The dropout rescale is
+    // folded into the GELU constants and the mask is applied to the PACKED results (drop masks from packed 16-bit arithmetic,
+    // one AND-NOT per result dword): 22 instead of 27 VALU instructions per element; the keep set is dropout_mask8's bit for bit
+    constexpr bool kUp = sizeof(TO) == 2 && FL >= 0 && (FL & ECGVIT_EPI_GELU) && (FL & ECGVIT_EPI_GELU_GRAD_AUX) &&
+                         !(FL & (ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_RESIDUAL | ECGVIT_EPI_ACCUM));
+    if constexpr (kUp) {
+        constexpr bool kDrop = (FL & ECGVIT_EPI_DROPOUT) != 0;
+        const float kk = kDrop ? e.inv_keep : 1.0f;
+        const float hk = ECGVIT_GELU_HK1 * kk, ck = ECGVIT_GELU_CK1 * kk;   // kk == 1: the very constants every other kernel uses
+        float dy[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gelu_fast_both_scaled(v[k], hk, ck, v[k], dy[k]);
+        u32x4 sav, out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sav[k] = pack_bf16x2(dy[2 * k], dy[2 * k + 1]); out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]); }
+        if constexpr (kDrop) {
+            uint32_t dm[4];
+            dropmask8(e.seed, m * (uint32_t)e.N + ncol, ((e.drop_thresh ^ 0x8000u) & 0xFFFFu) * 0x10001u, dm);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, 0);
+        nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
+        return;
     }
     if constexpr (sizeof(TO) == 2) {
         float mult[8];
@@ -156,33 +217,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, 0);
-        if (NT_HAS(ECGVIT_EPI_COLSUM)) {   // of the values as stored; masked lanes add nothing
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { cs8[2 * k] += ok ? bf16_lo(out[k]) : 0.f; cs8[2 * k + 1] += ok ? bf16_hi(out[k]) : 0.f; }
-        }
-        if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // the 8-bit copy of the values as stored (what a separate quantise pass would read back)
-            float f[8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { f[2 * k] = bf16_lo(out[k]); f[2 * k + 1] = bf16_hi(out[k]); }
-            if (ok) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) qmax = fmaxf(qmax, fabsf(f[k]));
-            }
-            const float mx = bf.q8_bf8 ? 57344.f : 448.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = __builtin_amdgcn_fmed3f(f[k] * bf.q8_inv, -mx, mx);
-            int w0 = 0, w1 = 0;
-            if (bf.q8_bf8) {
-                w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
-                w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
-            } else {
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
-            }
-            u32x2 q;
-            q[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w0); q[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w1);
-            __builtin_amdgcn_raw_buffer_store_b64(q, bf.q8, okm ? mm * (uint32_t)bf.ldq + ncm : NT_OOB, 0, 0);
-        }
+        nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax, e.flags);
     } else {   // f32 outputs: 32 B per lane stay in the accumulator layout (no train-step launch takes this branch)
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
         if (NT_HAS(ECGVIT_EPI_ACCUM)) {
@@ -200,9 +235,13 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 
 // Drain one wave's 128 x 64 accumulator block straight from registers.  acc[i][j][r] = C[row 16i + (lane&15)]
 // [col 32*(j>>1) + 8*(lane>>4) + 4*(j&1) + r] of the wave tile.
-template <typename TO, int FL>
+// `issue_next` puts the next tile's first operand pieces in flight (the kernel's prefetch, see the call site).  It runs AFTER the epilogue's
+// own up-front loads (bias, residual / aux rows) and BEFORE its first store: vmcnt retires in issue order, so pieces issued ahead of
+// those loads would have to land (an HBM round trip, with the matrix pipe idle) before the first row of the epilogue could start,
+// and pieces issued behind the stores would hold the next main loop until the stores are acknowledged.
+template <typename TO, int FL, typename IssueNext>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gemm_desc &d, const EpiParams &e, const NtBufs &bf, int m0, int n0,
-                                            int wave, int lane) {
+                                            int wave, int lane, IssueNext &&issue_next) {
     const int wm = wave >> 2, wn = wave & 3;
     const int c = lane & 15, q = lane >> 4;
     const int M = d.M, N = d.N;
@@ -248,6 +287,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) { R[i][h] = ld_res(i, h); X[i][h] = ld_aux(i, h); }
+        issue_next();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v0[8], v1[8];
@@ -263,6 +303,13 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         // heavy bodies must exist ONCE in the instruction stream (I-cache): rolled loop, only the accumulator pick is a switch;
         // row loads one step ahead
         u32x4 nr0 = ld_res(0, 0), nr1 = ld_res(0, 1), na0 = ld_aux(0, 0), na1 = ld_aux(0, 1);
+        // hipcc's wait-count model does not see LDS-DMA: behind the pieces it would wait `vmcnt(0)` for the bias (all of it is needed by
+        // the first row), i.e. for the pieces too.  Consume the bias here, while only the epilogue's own loads are in flight
+        if (NT_HAS(ECGVIT_EPI_BIAS)) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(bias[k]));
+        }
+        issue_next();
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
             const u32x4 r0 = nr0, r1 = nr1, a0 = na0, a1 = na1;
@@ -593,15 +640,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
         // Issue what the next tile's K-tile 0 would issue -- B(1), A(2) -- NOW, ahead of the epilogue's stores: vmcnt retires in
         // issue order, so a counted wait that sits BEHIND the stores stalls the next main loop until they are acknowledged; this
         // way the first wait that covers them comes two K-tiles later.  (The trailing group has sent B(1)'s first half already.)
-        if (a_ok && b_ok && has_next) {
-            if (!late) R_DMA_B(0, gb ^ 1, b_base + b_kt * (BK * 2));
-            R_DMA_B(1, gb ^ 1, b_base + b_kt * (BK * 2)); R_ADV_B();
-            const int gaf = ga == 0 ? 2 : ga - 1;
-            R_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); R_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); R_ADV_A();
-            pre = true;
-        }
+        // (Issued from inside the epilogue, behind its up-front row loads: see nt_epilogue.)
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            if (a_ok && b_ok && has_next) {
+                if (!late) R_DMA_B(0, gb ^ 1, b_base + b_kt * (BK * 2));
+                R_DMA_B(1, gb ^ 1, b_base + b_kt * (BK * 2)); R_ADV_B();
+                const int gaf = ga == 0 ? 2 : ga - 1;
+                R_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); R_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); R_ADV_A();
+                pre = true;
+            }
+        };
         [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
-        nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane);
+        nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next);
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
         if (!has_next) break;
         it = next_it;
