@@ -116,12 +116,17 @@ __device__ __forceinline__ bf16x8 tr_frag_c(const char *img_row0, int lo, int hi
     return join_halves(a, b);
 }
 
-// pack accumulator registers 8*ss .. 8*ss+7 (x optional multipliers) into the bf16 B-operand fragment
+// pack accumulator registers 8*ss .. 8*ss+7 into the bf16 B-operand fragment: explicit PAIRS (one v_cvt_pk_bf16_f32 per two values;
+// element-wise casts compile to one convert per value plus a v_perm per pair)
 __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
-    bf16x8 o;
+    typedef float f32x2_p __attribute__((ext_vector_type(2)));
+    u32x4 u;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)x[8 * ss + j];
-    return o;
+    for (int j = 0; j < 4; ++j) {
+        f32x2_p v; v[0] = x[8 * ss + 2 * j]; v[1] = x[8 * ss + 2 * j + 1];
+        u[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    }
+    return __builtin_bit_cast(bf16x8, u);
 }
 
 // =====================================================================================================
@@ -185,10 +190,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
             const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0
             m = mn;
+            const float mc = mn * c;
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f((s[r] - mn) * c);   // argument <= 0: no range fix-up needed
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));   // one fma per score (the kernel is VALU-bound); argument <= 0 up to rounding
                 s[r] = p;
                 ls += p;
             }
@@ -480,7 +486,8 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char *p) { return (uint32_
 
 // Records longer than 256 tokens (N <= 512, e.g. patch 10 -> 501) run as TWO launches, one per half of the keys: `k0` is the first key
 // of this launch's 256-key window, queries always run over all of N; the second launch adds its dQ to the first one's (ACCUM).
-template <bool DROP, bool ACCUM>
+// PRIO: static wave priority for the whole kernel (no per-phase flips): 0 none, 1 waves 4-7 raised, 2 waves 0-3 raised
+template <bool DROP, bool ACCUM, bool STAGGER = true, int PRIO = 1>
 __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                             const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                             bf16_t *__restrict__ dqkv, int N, int h, float scale, uint64_t seed,
@@ -599,8 +606,17 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 
     // the second-dispatched half of the workgroup loses VALU arbitration to the older half in every block (priority, then age): one
     // static priority raise for it, no per-phase flips (guide: two waves per SIMD, item 4)
-    if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 1 && late) __builtin_amdgcn_s_setprio(1);
+    if (PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
     unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
+#ifdef ECGVIT_TOOLS
+    // tools build only: per-PHASE stamps of the second item, one record per wave group (lane 0 of waves 0 and 4), behind the 768 block
+    // records of the buffer: [768 + block][group][query block][phase 0..7 = start, issue, A, V, B+W, C, wait, barrier]
+    unsigned long long *pstamps = (g_attn_stamps && (lane == 0) && (wave == 0 || wave == 4)) ? g_attn_stamps + (768 + (int64_t)blockIdx.x) * 128 + (wave >> 2) * 64 : nullptr;
+#define PH_STAMP(QB, IDX) do { if (pstamps && item_no == 1 && (QB) < 8) pstamps[(QB) * 8 + (IDX)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PH_STAMP(QB, IDX) do { } while (0)
+#endif
     int item_no = 0;
     int slot = 0, par = 0, jj = 0;   // ring slot of the current slab, K / LSE buffer of the current item, running slab counter (delta / dS parity)
     for (;;) {
@@ -616,24 +632,26 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             for (int r = 0; r < 16; ++r) { dKt[dt][r] = 0.f; dVt[dt][r] = 0.f; }
 
         if (stamps && threadIdx.x == 0 && item_no < 4) stamps[item_no * 32] = __builtin_amdgcn_s_memtime();
-        for (int qb = 0; qb < nqb; ++qb, ++jj) {
+        // ---- one query block = phases  issue | A: S, dP (8 MFMA) | V: softmax / dropout / dS arithmetic (VALU) | B: dV, dK (8 MFMA) |
+        // W: dS -> LDS | wait + barrier | C: dQ tile (8 small MFMA) + store.  Block j lives in ring slot (slot0 + j) & 3 and uses
+        // delta / dS buffer (jj0 + j) & 1.
+        const int slot0 = slot, jj0 = jj;
+        f32x16 s, dp;            // scores / dP accumulators of the block whose A phase ran last
+        uint32_t Pk[8], Dk[8];   // bf16 pairs (2m, 2m+1) of P (dropped) and dS: MFMA B operands AND the dS^T image rows
+        auto ph_issue = [&](int qb) __attribute__((always_inline)) {
+            const int sl = (slot0 + qb) & 3;
             // ---- feed the stream: next item's K / V / LSE once, slab qb+3 (of this item or the first slabs of the next)
             if (has_next && qb == 1) {
                 dma_k(nxt, Kimg0 + (par ^ 1) * IMG);
                 lse_n = load_lse(nxt);
             }
-            if (qb + 3 < nqb) dma_slab(cur, qb + 3, (slot + 3) & 3);
-            else if (has_next) dma_slab(nxt, qb + 3 - nqb, (slot + 3) & 3);
+            if (qb + 3 < nqb) dma_slab(cur, qb + 3, (sl + 3) & 3);
+            else if (has_next) dma_slab(nxt, qb + 3 - nqb, (sl + 3) & 3);
             // delta of the NEXT slab (visible since the previous barrier), published by this iteration's barrier
-            slab_delta((slot + 1) & 3, (jj + 1) & 1);
-
-            const char *Qrow = slab0 + slot * SLAB, *dOrow = Qrow + 4096;
-            const float *delta_c = delta_s + (jj & 1) * 32;
-            const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
-            const uint32_t hstep = qpitch * ECGVIT_WEYL;
-            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * qpitch + (uint32_t)((mykey + k0) >> 2)) * ECGVIT_WEYL;
-            const uint32_t bsh = (uint32_t)((mykey + k0) & 3) * 8u, lq = (uint32_t)(lane & 3);
-            f32x16 s, dp;
+            slab_delta((sl + 1) & 3, (jj0 + qb + 1) & 1);
+        };
+        auto ph_A = [&](int qb) __attribute__((always_inline)) {
+            const char *Qrow = slab0 + ((slot0 + qb) & 3) * SLAB, *dOrow = Qrow + 4096;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -641,6 +659,13 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Qrow, ro.ks[ks]), row_frag_c(Kimg + wave * 4096, ro.ks[ks]), s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(dOrow, ro.ks[ks]), vf[ks], dp, 0, 0, 0);
             }
+        };
+        auto ph_V = [&](int qb) __attribute__((always_inline)) {
+            const float *delta_c = delta_s + ((jj0 + qb) & 1) * 32;
+            const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
+            const uint32_t hstep = qpitch * ECGVIT_WEYL;
+            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * qpitch + (uint32_t)((mykey + k0) >> 2)) * ECGVIT_WEYL;
+            const uint32_t bsh = (uint32_t)((mykey + k0) & 3) * 8u, lq = (uint32_t)(lane & 3);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_c[qb * 32 + 8 * g4 + 4 * lh]);
@@ -668,39 +693,41 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                     dp[r] = p * (g - d4[k]) * scale;
                 }
             }
-            uint32_t Pk[8], Dk[8];   // bf16 pairs (2m, 2m+1) of P (dropped) and dS: MFMA B operands AND the dS^T image rows
 #pragma unroll
             for (int m = 0; m < 8; ++m) { Pk[m] = cvt_pk_bf16(s[2 * m], s[2 * m + 1]); Dk[m] = cvt_pk_bf16(dp[2 * m], dp[2 * m + 1]); }
-            {
-                uint32_t qa[4], da[4];
+        };
+        auto ph_B = [&](int qb) __attribute__((always_inline)) {
+            const char *Qrow = slab0 + ((slot0 + qb) & 3) * SLAB, *dOrow = Qrow + 4096;
+            uint32_t qa[4], da[4];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    qa[2 * dt] = lds_addr_of(Qrow) + to.lo[dt]; qa[2 * dt + 1] = lds_addr_of(Qrow) + to.hi[dt];
-                    da[2 * dt] = lds_addr_of(dOrow) + to.lo[dt]; da[2 * dt + 1] = lds_addr_of(dOrow) + to.hi[dt];
-                }
-#define TRG(SS)                                                                                                             \
-                {                                                                                                           \
-                    bf16x4 t[8];                                                                                            \
-                    t[0] = tr_read_asm_o<SS * 2048>(da[0]); t[1] = tr_read_asm_o<SS * 2048>(da[1]);                         \
-                    t[2] = tr_read_asm_o<SS * 2048>(qa[0]); t[3] = tr_read_asm_o<SS * 2048>(qa[1]);                         \
-                    t[4] = tr_read_asm_o<SS * 2048>(da[2]); t[5] = tr_read_asm_o<SS * 2048>(da[3]);                         \
-                    t[6] = tr_read_asm_o<SS * 2048>(qa[2]); t[7] = tr_read_asm_o<SS * 2048>(qa[3]);                         \
-                    u32x4 pu, du;                                                                                           \
-                    pu[0] = Pk[4 * SS]; pu[1] = Pk[4 * SS + 1]; pu[2] = Pk[4 * SS + 2]; pu[3] = Pk[4 * SS + 3];             \
-                    du[0] = Dk[4 * SS]; du[1] = Dk[4 * SS + 1]; du[2] = Dk[4 * SS + 2]; du[3] = Dk[4 * SS + 3];             \
-                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), dsf = __builtin_bit_cast(bf16x8, du);                 \
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-                    __builtin_amdgcn_sched_barrier(0);                                                                      \
-                    dVt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[0], t[1]), pf, dVt[0], 0, 0, 0);         \
-                    dKt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[2], t[3]), dsf, dKt[0], 0, 0, 0);        \
-                    dVt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[4], t[5]), pf, dVt[1], 0, 0, 0);         \
-                    dKt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[6], t[7]), dsf, dKt[1], 0, 0, 0);        \
-                }
-                TRG(0)
-                TRG(1)
-#undef TRG
+            for (int dt = 0; dt < 2; ++dt) {
+                qa[2 * dt] = lds_addr_of(Qrow) + to.lo[dt]; qa[2 * dt + 1] = lds_addr_of(Qrow) + to.hi[dt];
+                da[2 * dt] = lds_addr_of(dOrow) + to.lo[dt]; da[2 * dt + 1] = lds_addr_of(dOrow) + to.hi[dt];
             }
-            char *dsb = dSimg + (jj & 1) * DSB;
+#define TRG(SS)                                                                                                             \
+            {                                                                                                               \
+                bf16x4 t[8];                                                                                                \
+                t[0] = tr_read_asm_o<SS * 2048>(da[0]); t[1] = tr_read_asm_o<SS * 2048>(da[1]);                             \
+                t[2] = tr_read_asm_o<SS * 2048>(qa[0]); t[3] = tr_read_asm_o<SS * 2048>(qa[1]);                             \
+                t[4] = tr_read_asm_o<SS * 2048>(da[2]); t[5] = tr_read_asm_o<SS * 2048>(da[3]);                             \
+                t[6] = tr_read_asm_o<SS * 2048>(qa[2]); t[7] = tr_read_asm_o<SS * 2048>(qa[3]);                             \
+                u32x4 pu, du;                                                                                               \
+                pu[0] = Pk[4 * SS]; pu[1] = Pk[4 * SS + 1]; pu[2] = Pk[4 * SS + 2]; pu[3] = Pk[4 * SS + 3];                 \
+                du[0] = Dk[4 * SS]; du[1] = Dk[4 * SS + 1]; du[2] = Dk[4 * SS + 2]; du[3] = Dk[4 * SS + 3];                 \
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), dsf = __builtin_bit_cast(bf16x8, du);                     \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                          \
+                dVt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[0], t[1]), pf, dVt[0], 0, 0, 0);             \
+                dKt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[2], t[3]), dsf, dKt[0], 0, 0, 0);            \
+                dVt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[4], t[5]), pf, dVt[1], 0, 0, 0);             \
+                dKt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[6], t[7]), dsf, dKt[1], 0, 0, 0);            \
+            }
+            TRG(0)
+            TRG(1)
+#undef TRG
+        };
+        auto ph_W = [&](int qb) __attribute__((always_inline)) {
+            char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 u32x2 v;
@@ -708,9 +735,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 const int slt = 2 * g4 + lh;
                 *reinterpret_cast<u32x2 *>(dsb + mykey * 64 + ((slt ^ dsw(mykey)) << 3)) = v;
             }
-            // ---- the iteration's one wait + barrier.  Needed: my DMA pieces of slab qb+2 (issued one iteration ago).  Still allowed in
-            // flight, youngest first: this iteration's slab pieces (2 on waves 0-3, 1 on waves 4-7), the K / LSE prefetch of query
-            // block 1 (4 + 1), the previous dQ store -- or, on an item's first query block, the 8 dK / dV stores + last dQ store.
+        };
+        // ---- the block's one wait + barrier.  Needed: my DMA pieces of slab qb+2 (issued one block ago).  Still allowed in
+        // flight, youngest first: this block's slab pieces (2 on waves 0-3, 1 on waves 4-7), the K / LSE prefetch of query
+        // block 1 (4 + 1), one dQ store (the previous block's) -- or, on an item's first query block, the 8 dK / dV stores + last dQ store.
+        auto ph_waitbar = [&](int qb) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 1 + qb] = __builtin_amdgcn_s_memtime();
             if (!has_next) {
@@ -728,42 +757,101 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             __builtin_amdgcn_s_barrier();
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 17 + qb] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
-            // the next item's V fragments start travelling in the last query block (s / dp / packs are dead: the registers are free)
+            // the next item's V fragments start travelling behind the item's last barrier
             if (has_next && qb == nqb - 1) load_v(nxt, vfn);
-            // ---- dQ tile of this wave (one 16 x 16 tile: qt = wave&1, dhc = wave>>1), then its store: the iteration's LAST memory operation
-            {
-                const int qt = wave & 1, dhc = wave >> 1;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const int aoff = dq_a[qt], boff = dq_b[dhc];
-                const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
+        };
+        // ---- dQ tile of this wave (one 16 x 16 tile: qt = wave&1, dhc = wave>>1), then its store
+        auto ph_C = [&](int qb) __attribute__((always_inline)) {
+            const char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
+            const int qt = wave & 1, dhc = wave >> 1;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int aoff = dq_a[qt], boff = dq_b[dhc];
+            const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
 #define DQG(HF)                                                                                                              \
-                {                                                                                                            \
-                    bf16x4 t[8];                                                                                             \
-                    t[0] = tr_read_asm_o<(2 * HF) * 2048>(sa); t[1] = tr_read_asm_o<(2 * HF) * 2048 + 1024>(sa);             \
-                    t[2] = tr_read_asm_o<(2 * HF) * 4096>(ka); t[3] = tr_read_asm_o<(2 * HF) * 4096 + 2048>(ka);             \
-                    t[4] = tr_read_asm_o<(2 * HF + 1) * 2048>(sa); t[5] = tr_read_asm_o<(2 * HF + 1) * 2048 + 1024>(sa);     \
-                    t[6] = tr_read_asm_o<(2 * HF + 1) * 4096>(ka); t[7] = tr_read_asm_o<(2 * HF + 1) * 4096 + 2048>(ka);     \
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
-                    __builtin_amdgcn_sched_barrier(0);                                                                       \
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[2], t[3]), join_halves(t[0], t[1]), acc, 0, 0, 0); \
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[6], t[7]), join_halves(t[4], t[5]), acc, 0, 0, 0); \
-                }
-                DQG(0) DQG(1) DQG(2) DQG(3)
-#undef DQG
-                const int q = qb * 32 + qt * 16 + dq_i;
-                bf16x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
-                const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
-                if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16)
-                    const bf16x4 o = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
-                }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
+            {                                                                                                                \
+                bf16x4 t[8];                                                                                                 \
+                t[0] = tr_read_asm_o<(2 * HF) * 2048>(sa); t[1] = tr_read_asm_o<(2 * HF) * 2048 + 1024>(sa);                 \
+                t[2] = tr_read_asm_o<(2 * HF) * 4096>(ka); t[3] = tr_read_asm_o<(2 * HF) * 4096 + 2048>(ka);                 \
+                t[4] = tr_read_asm_o<(2 * HF + 1) * 2048>(sa); t[5] = tr_read_asm_o<(2 * HF + 1) * 2048 + 1024>(sa);         \
+                t[6] = tr_read_asm_o<(2 * HF + 1) * 4096>(ka); t[7] = tr_read_asm_o<(2 * HF + 1) * 4096 + 2048>(ka);         \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[2], t[3]), join_halves(t[0], t[1]), acc, 0, 0, 0); \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[6], t[7]), join_halves(t[4], t[5]), acc, 0, 0, 0); \
             }
-            slot = (slot + 1) & 3;
+            DQG(0) DQG(1) DQG(2) DQG(3)
+#undef DQG
+            const int q = qb * 32 + qt * 16 + dq_i;
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
+            const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
+            if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16)
+                const bf16x4 o = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
+        };
+        // The two waves of a SIMD (w and w + 4) would run the same phases between the same barriers -- MFMA phases together, VALU
+        // phases together (22 % MFMA-busy, 43 % of wave time waiting).  Waves 4-7 run HALF A BLOCK LATE instead: between two
+        // barriers they do V, B, W of block j, then the dQ tile of block j-1 (its dS buffer is not rewritten before block j+1)
+        // and the S / dP products of block j+1 (its slab is visible since the barrier before), so that their VALU phase
+        // meets the leading group's MFMA phases (C, A) and their MFMA phases (B, C, A) meet its VALU phase.  Results are unchanged bit
+        // for bit: every block's arithmetic is the same instruction sequence, only its placement relative to the barriers moves.
+        if (!STAGGER || !late) {
+            for (int qb = 0; qb < nqb; ++qb) {
+                PH_STAMP(qb, 0);
+                ph_issue(qb);
+                PH_STAMP(qb, 1);
+                ph_A(qb);
+                PH_STAMP(qb, 2);
+                ph_V(qb);
+                PH_STAMP(qb, 3);
+                ph_B(qb);
+                ph_W(qb);
+                PH_STAMP(qb, 4);
+                PH_STAMP(qb, 5);
+                ph_waitbar(qb);
+                PH_STAMP(qb, 7);
+                ph_C(qb);
+            }
+        } else {
+            // (first and last block peeled: a conditionally executed A phase would merge two versions of the 32 accumulator registers)
+            ph_issue(0);
+            ph_A(0);
+            ph_V(0);
+            ph_W(0);
+            ph_B(0);
+            ph_A(1);
+            ph_waitbar(0);
+            for (int qb = 1; qb < nqb - 1; ++qb) {
+                PH_STAMP(qb, 0);
+                ph_issue(qb);
+                PH_STAMP(qb, 1);
+                ph_V(qb);
+                PH_STAMP(qb, 3);
+                ph_W(qb);
+                ph_B(qb);
+                PH_STAMP(qb, 4);
+                ph_C(qb - 1);
+                PH_STAMP(qb, 5);
+                ph_A(qb + 1);
+                PH_STAMP(qb, 2);
+                ph_waitbar(qb);
+                PH_STAMP(qb, 7);
+            }
+            ph_issue(nqb - 1);
+            ph_V(nqb - 1);
+            ph_W(nqb - 1);
+            ph_B(nqb - 1);
+            ph_C(nqb - 2);
+            ph_waitbar(nqb - 1);
+            ph_C(nqb - 1);
         }
+#undef PH_STAMP
+        slot = (slot0 + nqb) & 3;
+        jj = jj0 + nqb;
         if (stamps && threadIdx.x == 0 && item_no < 4) stamps[item_no * 32 + 25] = __builtin_amdgcn_s_memtime();
         // ---- item done: dK^T / dV^T (dh on rows, key on the lane) -> this wave's 32 [key][dh] rows in a private 4-KiB patch -> 128-B rows
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -876,6 +964,11 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t *__restric
 
 }  // namespace
 
+#ifdef ECGVIT_TOOLS
+static int g_tools_attn_variant = -1;
+extern "C" int ecgvit_tools_attn_variant(int v) { g_tools_attn_variant = v; return ECGVIT_OK; }
+#endif
+
 extern "C" {
 
 int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 768 workgroups x 128 uint64 cycle stamps written by the persistent backward; NULL = off
@@ -944,7 +1037,22 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     // three workgroups' worth of items per CU slot: the hardware dispatcher hands them out as CUs free up, so a launch that shares the
     // GPU with a collective's kernels is not left with late workgroups a full static share behind (one per CU measured the same alone)
     const dim3 pg((unsigned)(nitems < 768 ? nitems : 768));
-#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0)
+#define PERS_ARGS(K0) pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0
+#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), PERS_ARGS(K0))
+#ifdef ECGVIT_TOOLS
+    if (g_tools_attn_variant >= 0 && th && N <= 256) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)
+        switch (g_tools_attn_variant) {
+            case 0: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 1>), PERS_ARGS(0)); break;   // round-2 kernel
+            case 1: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 0>), PERS_ARGS(0)); break;
+            case 2: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 1>), PERS_ARGS(0)); break;
+            case 3: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 0>), PERS_ARGS(0)); break;
+            case 4: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 2>), PERS_ARGS(0)); break;
+            default: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 2>), PERS_ARGS(0)); break;
+        }
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
+#endif
     if (th) PERS(true, false, 0); else PERS(false, false, 0);
     ECGVIT_CHECK_LAUNCH();
     if (N > 256) {   // second window of keys; its dQ accumulates on the first launch's (stream order)
