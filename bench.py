@@ -19,6 +19,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes, null
                 (with the reason in `traffic_source`) when the kernel sources changed since that profile was taken.
   masked        (N = 1, default workload) the build's masked pre-train step timed in the same process: value, ms_per_step, roofline.
+  fp8_large     (N = 1, default workload) BASELINE.json configs[4] on one GPU: EcgVit-large / 501 tokens with fp8 Linear operands, and the
+                same step with bf16 operands back to back on the same device (value, ms_per_step, fp8_over_bf16, roofline vs 5 PFLOP/s).
   cpu_baseline  the CPU oracle's train step (torch eager f32, all host cores) on a bounded sample of the same workload.
 """
 import argparse
@@ -219,6 +221,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
     ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
+    ap.add_argument('--no-fp8-large', action='store_true', help='skip the nested EcgVit-large fp8 / bf16 measurement (BASELINE.json configs[4] on one GPU)')
     ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
     ap.add_argument('--single-rank-collectives', action='store_true',
                     help='diagnostic, --gpus 1 only: a 1-rank RCCL group with the N > 1 code path switched on (self-launcher, start broadcast, '
@@ -301,7 +304,7 @@ def main():
 
     rank_times = {}
 
-    def timed_run(objective, steps, warmup):
+    def timed_run(objective, steps, warmup, conf=conf, batch=batch, dtype=dtype, fp8=fp8):
         """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result)"""
         torch.manual_seed(77)  # identical initial weights on every rank (HipTrainStep broadcasts rank 0's anyway)
         model = E.EcgVit(config=conf, compute_dtype=dtype, fp8_linear=fp8)
@@ -347,10 +350,10 @@ def main():
         rank_times[objective] = [1e3 * d / steps for d in rank_dt]
         return dt, final_loss, (probe.result() if probe else None)
 
-    def roofline_of(r, objective):
+    def roofline_of(r, objective, **over):
         if not r:
             return None
-        margs = argparse.Namespace(**{**vars(args), 'objective': objective})
+        margs = argparse.Namespace(**{**vars(args), 'objective': objective, **over})
         traffic, source = pmc_traffic('gemm_nt', margs)
         peak = PEAK_FP8_TFLOPS if r['launches_8bit'] else PEAK_BF16_TFLOPS
         return {
@@ -374,6 +377,33 @@ def main():
                         f'L1 reconstruction of the masked patches; fwd+loss+bwd+clip+AdamW), dropout {conf.hidden_dropout_prob}, {batch} records/GPU',
             'value': batch * msteps / mdt, 'unit': 'records/s', 'steps': msteps, 'ms_per_step': 1e3 * mdt / msteps, 'final_loss': mloss,
             'roofline': roofline_of(mres, 'masked'),
+        }
+
+    fp8_line = None
+    if args.objective == 'supervised' and world == 1 and args.config == 'base' and args.dtype == 'bf16' and not args.no_fp8_large:
+        # BASELINE.json configs[4] on one GPU, driver-timed next to the headline step: EcgVit-large, patch 10 (501 tokens), 256 records,
+        # fp8 (e4m3 / e5m2) Linear operands -- and the same step with bf16 operands, back to back on this device, for the ratio
+        import gc
+        lconf, lbatch = make_config(E, 'large', 10, args.length, args.dropout)
+        lsteps, lwarm = min(args.steps, 6), min(args.warmup, 2)
+        res = {}
+        for tag, f8 in (('bf16', False), ('fp8', True)):
+            gc.collect()
+            torch.cuda.empty_cache()
+            ldt, lloss, lres = timed_run('supervised', lsteps, lwarm, conf=lconf, batch=lbatch, dtype=torch.bfloat16, fp8=f8)
+            res[tag] = (ldt, lloss, lres)
+        gc.collect()
+        torch.cuda.empty_cache()
+        lflops = E.workload.train_flops_per_record(lconf)
+        v8, v16 = lbatch * lsteps / res['fp8'][0], lbatch * lsteps / res['bf16'][0]
+        fp8_line = {
+            'workload': f'EcgVit-large supervised BCE train step, fp8 Linear operands (e4m3 activations / weights, e5m2 gradients on the block-scaled fp8 MFMA; '
+                        f'bf16 weight gradients, attention, LayerNorm), patch 10 ({lconf.max_signal_length // 10 + 1} tokens), dropout {lconf.hidden_dropout_prob}, {lbatch} records/GPU',
+            'value': v8, 'unit': 'records/s', 'steps': lsteps, 'ms_per_step': 1e3 * res['fp8'][0] / lsteps, 'final_loss': res['fp8'][1],
+            'bf16_same_config': {'value': v16, 'ms_per_step': 1e3 * res['bf16'][0] / lsteps, 'final_loss': res['bf16'][1]},
+            'fp8_over_bf16': v8 / v16,
+            'model_tflops_per_gpu': v8 * lflops / 1e12, 'frac_of_fp8_peak': v8 * lflops / 1e12 / PEAK_FP8_TFLOPS,
+            'roofline': roofline_of(res['fp8'][2], 'supervised', config='large', dtype='fp8', patch=10, batch=lbatch),
         }
 
     if rank == 0:
@@ -406,6 +436,8 @@ def main():
             out['roofline'] = roofline_of(pres, args.objective)
         if masked_line:
             out['masked'] = masked_line
+        if fp8_line:
+            out['fp8_large'] = fp8_line
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(conf, masked=args.objective == 'masked')
         print(json.dumps(out), flush=True)
