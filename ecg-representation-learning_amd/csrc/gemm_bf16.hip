@@ -308,6 +308,7 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);
 
 extern "C" int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d) {
+    if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && d->layout == ECGVIT_GEMM_TN) return ecgvit_gemm_wgrad_workspace(d);
     if (d->dtype != ECGVIT_BF16 || d->layout != ECGVIT_GEMM_TN) return 0;
     const int ntile = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
     const int s = choose_splits(d, ntile);
@@ -399,6 +400,12 @@ static int gemm_dispatch(const ecgvit_gemm_desc *d, void *stream, int *route) {
     }
     if (d->dtype == ECGVIT_F32) return ecgvit_gemm_f32_launch(d, as_stream(stream), route);
     if (d->dtype == ECGVIT_BF16) return ecgvit_gemm_bf16_launch(d, as_stream(stream), route);
+    if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && d->layout == ECGVIT_GEMM_TN) {
+        // 8-bit weight gradients dW = dY8^T . X8 (A in `dtype`, B e4m3, f32 output): the streaming split-K kernel only
+        if (!d->C || reinterpret_cast<uintptr_t>(d->C) % 16 || d->ldc % 4 || !ecgvit_gemm_wgrad_applicable(d)) return ECGVIT_EINVAL;
+        if (route) { *route = ECGVIT_KERNEL_GEMM_WGRAD; return ECGVIT_OK; }
+        return ecgvit_gemm_wgrad_launch(d, as_stream(stream));
+    }
     if (d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) {   // 8-bit operands: the large A . B^T kernel only (no small-shape fallback)
         if (!d->A || !d->B || !d->C || (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16) return ECGVIT_EINVAL;
         if ((d->epilogue & ECGVIT_EPI_BIAS) && (!d->bias || reinterpret_cast<uintptr_t>(d->bias) % 16)) return ECGVIT_EINVAL;

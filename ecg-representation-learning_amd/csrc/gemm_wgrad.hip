@@ -343,9 +343,168 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_kernel(ecgvit_gemm_desc d, 
     epilogue_store<TO>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel on 8-BIT operands (fp8_linear; BASELINE.json configs[4]): dW = dY8^T . X8 with dY8 in e5m2 (or e4m3) and X8 in e4m3,
+// both k-major ([token rows][features], one byte per element -- the copies the forward / input-gradient products already own), on the
+// block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate).  A K-tile is 128 token rows deep in
+// the same 32-KiB tile ([128 k][256 mn] bytes, 256-B rows): the same DMA pieces, barriers and counted waits as above, four phases of
+// 4 MFMAs (64 cycles each) per K-tile, i.e. twice the K per byte that crosses the CU's memory path.
+// Fragments come from `ds_read_b64_tr_b8` (probed on the device, tools/probe_tr8.hip): in a 16-lane group source lane s supplies the
+// 8 bytes at ITS address and result lane i receives byte (i & 7) of source lanes 2j + (i >> 3), j = 0..7 -- with source lane s pointing
+// at k-row s >> 1, bytes 8 (s & 1) .. +7 of a 16-byte column chunk, lane i ends up with 8 consecutive k of column i.  Four such reads
+// (k = 32 hb + 8 t + j) are the 32 operand bytes of one lane (row lane & 31, k-half hb = lane >> 5); A and B use the same k order.
+// Image swizzle (on the per-lane SOURCE address of the DMA): 16-B chunk ^= (k & 7) << 1 -- the 8 k-rows x 2 column chunks a 32-lane
+// read cycle touches land on 16 distinct 16-B slots of the 256-B bank row.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ FastOp fast_setup8(const uint8_t *P, int64_t ld, int mn0, int kend, int wave, int lane) {
+    FastOp f;
+    f.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P, 0, (uint32_t)((int64_t)kend * ld), 0x00020000);   // rows >= kend read as zero
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = (wave * 4 + i) * 4 + (lane >> 4);          // k-row of this lane inside the K-tile (a piece = 4 rows x 256 B)
+        const int c = (lane & 15) ^ ((kr & 7) << 1);
+        f.voff[i] = (int)((int64_t)kr * ld + mn0 + c * 16);
+    }
+    return f;
+}
+template <int I0 = 0, int I1 = 4>
+__device__ __forceinline__ void fast_dma8(const FastOp &f, int64_t ld, int k0, char *tile, int wave) {
+    const int soff = (int)((int64_t)k0 * ld);
+#pragma unroll
+    for (int i = I0; i < I1; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(f.rsrc, (lptr_t)(tile + (wave * 4 + i) * 1024), 16, f.voff[i], soff, 0, 0);
+}
+// per-lane byte offset (inside a tile image) of the lane's first transposed read for a 32-column block starting at column mn_base (a
+// multiple of 32); read t of k-step ks adds 16384 ks + 2048 t
+__device__ __forceinline__ uint32_t frag8_lane_off(int mn_base, int lane) {
+    const int s = lane & 15, j = s >> 1;
+    const int chunk = (mn_base >> 4) + ((lane >> 4) & 1);
+    return (uint32_t)((32 * (lane >> 5) + j) * 256 + ((chunk ^ (j << 1)) << 4) + 8 * (s & 1));
+}
+template <int KS> __device__ __forceinline__ i32x8_t frag8(uint32_t lds_addr) {
+    u32x2 t0, t1, t2, t3;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(t0) : "v"(lds_addr), "n"(KS * 16384) : "memory");
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(t1) : "v"(lds_addr), "n"(KS * 16384 + 2048) : "memory");
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(t2) : "v"(lds_addr), "n"(KS * 16384 + 4096) : "memory");
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(t3) : "v"(lds_addr), "n"(KS * 16384 + 6144) : "memory");
+    return i32x8_t{(int)t0[0], (int)t0[1], (int)t1[0], (int)t1[1], (int)t2[0], (int)t2[1], (int)t3[0], (int)t3[1]};
+}
+
+template <int AFMT>   // format of A (= dY): 0 e4m3, 1 e5m2; B (= X) is e4m3
+__global__ __launch_bounds__(512, 2) void gemm_wgrad8_kernel(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    constexpr int BK8 = 128;
+    const int ntile = tiles_m * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else if (sk.splits > 1) {
+        const int gid = xcd_remap(blockIdx.x, ntile * sk.splits);
+        split = gid / ntile;
+        tid = gid - split * ntile;
+    } else {
+        split = 0;
+        tid = xcd_remap(blockIdx.x, ntile);
+    }
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const int nk = (kend - kbeg + BK8 - 1) / BK8;
+    const uint8_t *A = reinterpret_cast<const uint8_t *>(d.A);
+    const uint8_t *B = reinterpret_cast<const uint8_t *>(d.B);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wm == 1;
+    if (d.scale_a) e.alpha *= *d.scale_a;     // per-tensor scales of the 8-bit operands (device scalars); the split-K reducer applies them
+    if (d.scale_b) e.alpha *= *d.scale_b;     // itself when the partial sums go through slabs
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const FastOp fa = fast_setup8(A, d.lda, m0, kend, wave, lane);
+    const FastOp fb = fast_setup8(B, d.ldb, n0, kend, wave, lane);
+    char *const ringA = smem, *const ringB = smem + 3 * TILE_BYTES;
+    uint32_t offA[4], offB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offA[i] = frag8_lane_off(wm * 128 + i * 32, lane);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offB[j] = frag8_lane_off(wn * 64 + j * 32, lane);
+    // prologue: A(0), B(0), A(1)
+    fast_dma8(fa, d.lda, kbeg, ringA, wave);
+    fast_dma8(fb, d.ldb, kbeg, ringB, wave);
+    if (nk > 1) {
+        fast_dma8(fa, d.lda, kbeg + BK8, ringA + TILE_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();
+
+    int ga = 0, gb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t sa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)(ringA + ga * TILE_BYTES);
+        const uint32_t sb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)(ringB + gb * TILE_BYTES);
+        char *nA = ringA + (ga == 0 ? 2 : ga - 1) * TILE_BYTES;   // slot of K-tile kt+2
+        char *nB = ringB + (gb ^ 1) * TILE_BYTES;                 // slot of K-tile kt+1
+        const bool b_ok = kt + 1 < nk, a_ok = kt + 2 < nk;
+        const int kB = kbeg + (kt + 1) * BK8, kA = kbeg + (kt + 2) * BK8;
+        i32x8_t b[2];
+        // phase p: k-step p >> 1 (64 token rows), A row blocks 2 (p & 1) .. +1: 16 or 8 transposed reads + 2 DMA pieces | 4 MFMAs
+#define W8_PHASE(P)                                                                                                          \
+        {                                                                                                                    \
+            constexpr int KS = (P) >> 1, IH = (P) & 1;                                                                       \
+            i32x8_t a[2];                                                                                                    \
+            if (IH == 0) { b[0] = frag8<KS>(sb + offB[0]); b[1] = frag8<KS>(sb + offB[1]); }                                 \
+            a[0] = frag8<KS>(sa + offA[2 * IH]); a[1] = frag8<KS>(sa + offA[2 * IH + 1]);                                    \
+            if ((P) == 0) { if (b_ok) fast_dma8<0, 2>(fb, d.ldb, kB, nB, wave); }                                            \
+            else if ((P) == 1) { if (b_ok) fast_dma8<2, 4>(fb, d.ldb, kB, nB, wave); }                                       \
+            else if ((P) == 2) { if (a_ok) fast_dma8<0, 2>(fa, d.lda, kA, nA, wave); }                                       \
+            else {                                                                                                           \
+                if (a_ok) { fast_dma8<2, 4>(fa, d.lda, kA, nA, wave); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }     \
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+            }                                                                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            __builtin_amdgcn_s_barrier();                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            __builtin_amdgcn_s_setprio(1);                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                      \
+                acc[2 * IH + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[2 * IH + i][j], AFMT, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+            __builtin_amdgcn_s_setprio(0);                                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            __builtin_amdgcn_s_barrier();                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+        }
+        W8_PHASE(0) W8_PHASE(1) W8_PHASE(2) W8_PHASE(3)
+#undef W8_PHASE
+        ga = ga == 2 ? 0 : ga + 1;
+        gb ^= 1;
+    }
+    if (!late) __builtin_amdgcn_s_barrier();   // re-align the two groups
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    epilogue_store<float>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
-                                                             TO *__restrict__ C, int64_t ldc, EpiParams e) {
+                                                             TO *__restrict__ C, int64_t ldc, EpiParams e,
+                                                             const float *__restrict__ scale_a = nullptr, const float *__restrict__ scale_b = nullptr) {
+    if (scale_a) e.alpha *= *scale_a;   // per-tensor scales of 8-bit operands
+    if (scale_b) e.alpha *= *scale_b;
     const int64_t nv = MN / 4;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         f32x4 s = *reinterpret_cast<const f32x4 *>(slabs + i * 4);
@@ -414,9 +573,16 @@ void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float 
 
 // large weight-gradient products only (both extents whole tiles, a long reduction); everything else stays on gemm_bf16.hip's 128^2 kernel
 bool ecgvit_gemm_wgrad_applicable(const ecgvit_gemm_desc *d) {
-    if (d->layout != ECGVIT_GEMM_TN || d->dtype != ECGVIT_BF16 || d->batch1 != 1 || d->batch2 != 1) return false;
+    const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
+    if (d->layout != ECGVIT_GEMM_TN || !(d->dtype == ECGVIT_BF16 || f8) || d->batch1 != 1 || d->batch2 != 1) return false;
     if (d->epilogue & ~(ECGVIT_EPI_BIAS | ECGVIT_EPI_ACCUM)) return false;
     if (d->K < 4096 || d->M % 256 != 0 || d->N % 256 != 0) return false;
+    if (f8) {   // 8-bit operands: f32 output, 16-B aligned rows (one DMA lane = 16 bytes of a row)
+        if (d->out_dtype != ECGVIT_F32 || d->lda % 16 || d->ldb % 16 || !d->A || !d->B ||
+            (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B)) % 16)
+            return false;
+        return (int64_t)d->K * d->lda + 65536 * d->lda < (1ll << 31) && (int64_t)d->K * d->ldb + 65536 * d->ldb < (1ll << 31);
+    }
     return (int64_t)d->K * d->lda * 2 + 65536 * d->lda < (1ll << 31) && (int64_t)d->K * d->ldb * 2 + 65536 * d->ldb < (1ll << 31);
 }
 
@@ -446,14 +612,21 @@ int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     }
     const EpiParams e = make_epi(d);
     const dim3 grid((unsigned)(ntile * sk.splits)), block(512);
-    if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+    const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
+    if (f8) {
+        // 8-bit K-tiles are 128 token rows deep: slice boundaries on multiples of 128
+        if (sk.splits > 1) sk.k_per_split = (((d->K + 127) / 128 + sk.splits - 1) / sk.splits) * 128;
+        if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(gemm_wgrad8_kernel<0>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+    } else if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
     else hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
     ECGVIT_CHECK_LAUNCH();
     if (sk.splits > 1) {
         const int64_t MN = (int64_t)d->M * d->N;
         const int g = (int)std::min<int64_t>((MN / 4 + 255) / 256, 2048);
         if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(splitk_reduce2_kernel<bf16_t>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (bf16_t *)d->C, d->ldc, e);
-        else hipLaunchKernelGGL(splitk_reduce2_kernel<float>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (float *)d->C, d->ldc, e);
+        else hipLaunchKernelGGL(splitk_reduce2_kernel<float>, dim3(g), dim3(256), 0, s, sk.slabs, sk.splits, MN, d->N, (float *)d->C, d->ldc, e,
+                                f8 ? d->scale_a : nullptr, f8 ? d->scale_b : nullptr);
         ECGVIT_CHECK_LAUNCH();
     }
     return ECGVIT_OK;

@@ -412,13 +412,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__
     }
 }
 
-template <int E, bool EXTRA>
+// Q8 (with EXTRA): additionally g8 = saturate(v / *q8_scale) in e5m2 for v = the gradient the next backward stage consumes (dxm when a
+// mask is applied, else dx), as stored -- the 8-bit A operand of that stage's input-gradient product, written here instead of by a
+// quantise pass -- and *q8_amax = max(*q8_amax, max |v|) for the next step's scale
+template <int E, bool EXTRA, bool Q8 = false>
 __global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel(const bf16_t *__restrict__ dy, const bf16_t *__restrict__ x,
                                                                 const float *__restrict__ gamma, const float *__restrict__ mean,
                                                                 const float *__restrict__ rstd, const bf16_t *__restrict__ dres,
                                                                 bf16_t *__restrict__ dx, float *__restrict__ partial, int64_t rows,
-                                                                bf16_t *__restrict__ dxm, uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                                bf16_t *__restrict__ dxm, uint64_t seed, uint32_t thresh, float inv_keep,
+                                                                uint8_t *__restrict__ g8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                                float *__restrict__ q8_amax = nullptr) {
     using L = LaneRow<E>;
+    [[maybe_unused]] float q8_inv = 0.f, qmax = 0.f;
+    if constexpr (Q8) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
     constexpr int d = 64 * E, NP = EXTRA ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4][NP][d] partial sums, then gamma [d]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -474,7 +481,35 @@ __global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel
             }
 #pragma unroll
             for (int k = 0; k < E; ++k) ac[k] += o[k];
+            if constexpr (Q8) {   // o = the values as stored (bf16-rounded), masked if a mask applies
+                uint8_t *row8 = g8 + ro;
+                float q[E];
+#pragma unroll
+                for (int k = 0; k < E; ++k) {
+                    qmax = fmaxf(qmax, fabsf(o[k]));
+                    q[k] = __builtin_amdgcn_fmed3f(o[k] * q8_inv, -57344.f, 57344.f);
+                }
+#pragma unroll
+                for (int i = 0; i < L::N16; ++i) {
+                    int w0 = 0, w1 = 0;
+                    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * i], q[8 * i + 1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * i + 2], q[8 * i + 3], w0, true);
+                    w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * i + 4], q[8 * i + 5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * i + 6], q[8 * i + 7], w1, true);
+                    u32x2 ov;
+                    ov[0] = (uint32_t)w0; ov[1] = (uint32_t)w1;
+                    *reinterpret_cast<u32x2 *>(row8 + (i * 64 + lane) * 8) = ov;
+                }
+                if constexpr (L::N8 == 1) {
+                    int w0 = 0;
+                    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * L::N16], q[8 * L::N16 + 1], w0, false);
+                    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[8 * L::N16 + 2], q[8 * L::N16 + 3], w0, true);
+                    *reinterpret_cast<uint32_t *>(row8 + 512 * L::N16 + 4 * lane) = (uint32_t)w0;
+                }
+            }
         }
+    }
+    if constexpr (Q8) {
+        qmax = wave_max(qmax);
+        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
     }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
@@ -712,7 +747,9 @@ int64_t ecgvit_layernorm_bwd_workspace(int64_t rows, int d) { return (int64_t)ln
 
 static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
                          void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, int dtype, void *stream,
-                         bool extra, void *dxm, float *dcolsum, float dropout_p, uint64_t seed) {
+                         bool extra, void *dxm, float *dcolsum, float dropout_p, uint64_t seed,
+                         void *g8 = nullptr, const float *q8_scale = nullptr, float *q8_amax = nullptr) {
+    if (g8 && (!extra || !q8_scale || !q8_amax || dtype != ECGVIT_BF16 || !ln_fit(d) || (int64_t)rows * d >= (1ll << 31))) return ECGVIT_EINVAL;
     if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048 || !partial) return ECGVIT_EINVAL;
     if (extra && (!dcolsum || (dropout_p > 0.f && !dxm) || ((int64_t)rows * d) % 2)) return ECGVIT_EINVAL;
     const int grid = ln_bwd_grid(rows);
@@ -725,7 +762,8 @@ static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, cons
         const size_t ldsf = lds + (size_t)d * 4;   // + gamma
 #define LN_FIT(EE)                                                                                                                \
     case EE:                                                                                                                      \
-        if (extra) hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, true>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)dxm, seed, th, ik); \
+        if (g8) hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, true, true>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)dxm, seed, th, ik, (uint8_t *)g8, q8_scale, q8_amax); \
+        else if (extra) hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, true>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)dxm, seed, th, ik); \
         else hipLaunchKernelGGL((layernorm_bwd_fit_kernel<EE, false>), dim3(grid), dim3(256), ldsf, as_stream(stream), (const bf16_t *)dy, (const bf16_t *)x, gamma, mean, rstd, (const bf16_t *)dres, (bf16_t *)dx, (float *)partial, rows, (bf16_t *)nullptr, seed, 0u, 1.f); \
         break;
         switch (d / 64) { LN_FIT(4) LN_FIT(8) LN_FIT(12) LN_FIT(16) LN_FIT(24) LN_FIT(32) default: return ECGVIT_EINVAL; }
@@ -759,6 +797,14 @@ int ecgvit_layernorm_bwd_fused(const void *dy, const void *x, const float *gamma
                                void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, void *dxm, float *dcolsum,
                                float dropout_p, uint64_t seed, int dtype, void *stream) {
     return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, partial, rows, d, dtype, stream, true, dxm, dcolsum, dropout_p, seed);
+}
+
+int ecgvit_layernorm_bwd_fused_q8(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                                  void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d, void *dxm, float *dcolsum,
+                                  float dropout_p, uint64_t seed, void *g8, const float *q8_scale, float *q8_amax, void *stream) {
+    if (!g8) return ECGVIT_EINVAL;
+    return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, partial, rows, d, ECGVIT_BF16, stream, true, dxm, dcolsum, dropout_p, seed,
+                         g8, q8_scale, q8_amax);
 }
 
 static int colsum_row_blocks(int64_t M) { return (int)std::min<int64_t>((M + 255) / 256, 256); }

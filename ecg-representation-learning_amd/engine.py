@@ -246,8 +246,8 @@ class VitEngine:
         """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one.
         Returns True when the 8-bit copy of dX was emitted for `emit_site` (fp8_linear)."""
         if self.fp8 and site is not None and M >= 2048 and name in self.w8_index:
-            if prequant:
-                q, sc = self.act['q8b'][:M * nout], self.f8_scale[site:site + 1]
+            if prequant:   # the producer already wrote dY's 8-bit copy: 'q8' (LayerNorm backward) or q8b (a GEMM epilogue)
+                q, sc = self.act['q8' if prequant == 'q8' else 'q8b'][:M * nout], self.f8_scale[site:site + 1]
             else:
                 q, sc = self._quant(site, dY, M * nout)
             emitted = emit_site is not None and self._emit8(kw, emit_site, kin)
@@ -325,11 +325,22 @@ class VitEngine:
         check(lib().ecgvit_layernorm_bwd(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
                                          ptr(self.act['ws']), rows, self.d, hip.code(self.dtype), stream()), 'layernorm_bwd')
 
-    def _ln_bwd_fused(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows, dxm, dcolsum, p, seed):
-        """LayerNorm backward that also emits, for the NEXT stage, the dropout-masked copy of dx and its column sums"""
+    def _ln_bwd_fused(self, dy, x, g, mean, rstd, dres, dx, dg, db, rows, dxm, dcolsum, p, seed, q8_site=None):
+        """LayerNorm backward that also emits, for the NEXT stage, the dropout-masked copy of dx and its column sums; q8_site
+        (fp8_linear): also the e5m2 copy of that gradient into the operand scratch for the input-gradient product that consumes it
+        (returns True), once the site has a scale and when the exact-fit kernel covers d"""
+        d = self.d
+        if (self.fp8 and q8_site is not None and q8_site in self._f8_seen and rows >= 2048 and d // 64 in (4, 8, 12, 16, 24, 32) and d % 64 == 0
+                and rows * d < 2 ** 31):
+            check(lib().ecgvit_layernorm_bwd_fused_q8(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
+                                                      ptr(self.act['ws']), rows, d, ptr(dxm), ptr(dcolsum), p, seed, ptr(self.act['q8']),
+                                                      ptr(self.f8_scale[q8_site:q8_site + 1]), ptr(self.f8_amax[q8_site:q8_site + 1]), stream()),
+                  'layernorm_bwd_fused_q8')
+            return True
         check(lib().ecgvit_layernorm_bwd_fused(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
                                                ptr(self.act['ws']), rows, self.d, ptr(dxm), ptr(dcolsum), p, seed,
                                                hip.code(self.dtype), stream()), 'layernorm_bwd_fused')
+        return False
 
     def _colsum(self, x, ld, out, M, N):
         check(lib().ecgvit_colsum(ptr(x), ld, ptr(out), ptr(self.act['ws']), M, N, hip.code(self.dtype), stream()), 'colsum')
@@ -596,6 +607,7 @@ class VitEngine:
         # after the first site, the fused LayerNorm backward of the previous stage has already produced it AND its bias gradient
         have = False
         dY = dX
+        pq4 = pq6 = False   # fp8_linear: the LayerNorm backward before a site already wrote its e5m2 operand copy
         for i in reversed(range(self.Ly)):
             L = a['layers'][i]
             lp = f'{pre}transformer.layers.{i}.'
@@ -614,18 +626,20 @@ class VitEngine:
                 epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
-            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, epilogue=epi, aux=L['hpre'],
+            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, prequant='q8' if pq4 else False,
+                             epilogue=epi, aux=L['hpre'],
                              ldaux=f, dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
             self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5, prequant=bool(dq))
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
-            self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
-                               G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2)
+            pq6 = self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
+                                     G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2,
+                                     q8_site=8 * i + 6)
             dX, other = other, dX  # dX = d(x1)
             dY = a['dxm'] if ph > 0 else dX
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
-            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6)
+            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6, prequant='q8' if pq6 else False)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
                                              dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
@@ -636,9 +650,9 @@ class VitEngine:
             if i > 0:
                 # LN1 backward; its output feeds layer i-1's FFN-down site (mask seed of layer i-1, bias net.3.bias)
                 lq = f'{pre}transformer.layers.{i - 1}.'
-                self._ln_bwd_fused(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
-                                   G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M, a['dxm'], G[lq + '1.fn.net.3.bias'], ph,
-                                   seed + 100 * i + 4)
+                pq4 = self._ln_bwd_fused(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,
+                                         G[lp + '0.norm.weight'], G[lp + '0.norm.bias'], M, a['dxm'], G[lq + '1.fn.net.3.bias'], ph,
+                                         seed + 100 * i + 4, q8_site=8 * (i - 1) + 4)
                 have = True
             else:
                 self._ln_bwd(a['dxn'], Xin, self.P32[lp + '0.norm.weight'], L['mean1'], L['rstd1'], dX, other,

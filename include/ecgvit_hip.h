@@ -73,7 +73,9 @@ int ecgvit_abi_version(void);
 typedef struct ecgvit_gemm_desc {
     int32_t layout;    /* ECGVIT_GEMM_*                                             */
     int32_t dtype;     /* element type of A and B: ECGVIT_F32 | ECGVIT_BF16; or ECGVIT_FP8_E4M3 | ECGVIT_BF8_E5M2 = the 8-bit
-                          format of A with B in e4m3 (ECGVIT_GEMM_NT only, K % 128 == 0, lda/ldb % 16 == 0, bf16 output) */
+                          format of A with B in e4m3: ECGVIT_GEMM_NT (K % 128 == 0, lda/ldb % 16 == 0, bf16 output), or ECGVIT_GEMM_TN
+                          = weight gradients dW = dY8^T . X8 (M, N % 256 == 0, K >= 4096, lda/ldb % 16 == 0, f32 output, bias / accumulate
+                          epilogues only; scale_a * scale_b is applied to the sum) */
     int32_t out_dtype; /* element type of C, aux, residual                          */
     int32_t epilogue;  /* OR of ECGVIT_EPI_*                                        */
     int32_t M, N, K;
@@ -170,6 +172,14 @@ int ecgvit_layernorm_bwd(const void *dy, const void *x, const float *gamma, cons
 int ecgvit_layernorm_bwd_fused(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
                                const void *dres, void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d,
                                void *dxm, float *dcolsum, float dropout_p, uint64_t seed, int dtype, void *stream);
+
+/* fp8 operand path: the same fused backward (bf16, d in 64 * {4, 8, 12, 16, 24, 32}) that also writes g8 = saturate(v / *q8_scale) in e5m2 for
+ * v = the gradient the next stage consumes (dxm when dropout_p > 0, else dx; as stored) and accumulates *q8_amax = max(*q8_amax, max |v|):
+ * the 8-bit A operand of that stage's input-gradient product, without a quantise pass over the gradient */
+int ecgvit_layernorm_bwd_fused_q8(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
+                                  const void *dres, void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d,
+                                  void *dxm, float *dcolsum, float dropout_p, uint64_t seed, void *g8, const float *q8_scale,
+                                  float *q8_amax, void *stream);
 
 /* out[i] = in[i] * keep(seed, i) / (1-p): re-applies an epilogue dropout mask (element index = m*N+n, contiguous [M,N])
  * to the incoming gradient of a `dropout(acc + bias) + residual` site.  in == out allowed. */

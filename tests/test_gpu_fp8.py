@@ -198,3 +198,71 @@ def test_full_large_fp8_configuration_properties():
     losses = [float(step.step(x, y)[0]) for _ in range(3)]
     step.finish()
     assert all(l == l and abs(l) < 1e4 for l in losses) and losses[2] < losses[0], losses
+
+
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_layernorm_bwd_emits_the_e5m2_copy_of_its_gradient(p):
+    """ecgvit_layernorm_bwd_fused_q8 = ecgvit_layernorm_bwd_fused bit for bit (dx, dxm, dgamma, dbeta, column sums) + the e5m2 copy of the
+    gradient the next stage consumes (dxm under dropout, dx without), equal to torch's float8_e5m2 cast of that tensor over the scale, and
+    its amax"""
+    rows, d = 4100, 1024
+    g = torch.Generator().manual_seed(21)
+    dy, x, dres = (torch.randn(rows, d, generator=g).to(BF16).cuda() for _ in range(3))
+    gamma = torch.randn(d, generator=g).cuda()
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    ws = torch.empty(lib().ecgvit_layernorm_bwd_workspace(rows, d), dtype=torch.uint8, device='cuda')
+
+    def run(q8):
+        dx, dxm = torch.zeros(rows, d, device='cuda', dtype=BF16), torch.zeros(rows, d, device='cuda', dtype=BF16)
+        dg, db, cs = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda')
+        if q8 is None:
+            check(lib().ecgvit_layernorm_bwd_fused(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, d,
+                                                   ptr(dxm), ptr(cs), p, 77, hip.BF16, stream()), 'ln_bwd_fused')
+        else:
+            g8, scale, amax = q8
+            check(lib().ecgvit_layernorm_bwd_fused_q8(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db), ptr(ws), rows, d,
+                                                      ptr(dxm), ptr(cs), p, 77, ptr(g8), ptr(scale), ptr(amax), stream()), 'ln_bwd_fused_q8')
+        return dx, dxm, dg, db, cs
+    ref = run(None)
+    grad = ref[1] if p > 0 else ref[0]
+    scale = (grad.float().abs().max() / 57344.0 * 1.5).reshape(1)        # a delayed scale: not exactly this tensor's
+    g8 = torch.full((rows, d), 0x7F, dtype=torch.uint8, device='cuda')
+    amax = torch.zeros(1, device='cuda')
+    got = run((g8, scale, amax))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert float(amax) == float(grad.float().abs().max())
+    want = (grad.float() * (1.0 / scale)).clamp(-57344.0, 57344.0).to(torch.float8_e5m2)
+    same = (g8.view(torch.float8_e5m2).view(torch.uint8) == want.view(torch.uint8)) | ((g8.view(torch.float8_e5m2).float() == 0) & (want.float() == 0))
+    assert float(same.float().mean()) > 0.9999
+
+
+@pytest.mark.parametrize('afmt', [hip.BF8_E5M2, hip.FP8_E4M3])
+@pytest.mark.parametrize('shape', [(512, 256, 70011), (1024, 3072, 16384), (256, 512, 4100)])
+def test_weight_gradient_8bit_operands_vs_f32_product(afmt, shape):
+    """dW = dY8^T . X8 on the 8-bit streaming split-K kernel (ds_read_b64_tr_b8 fragments, block-scaled 32x32x64 MFMA, unit block scales):
+    products of 8-bit values are exact in f32, so the result equals the f32 product of the dequantised operands up to summation order;
+    ragged K (token rows, not a multiple of 128: rows beyond the end read as zero), scales through device scalars; small integers exactly,
+    on repeated launches (race screen)"""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _rand8((K, M), FMT[afmt][0], g, 2.0).cuda()
+    B = _rand8((K, N), torch.float8_e4m3fn, g, 0.5).cuda()
+    sa, sb = torch.tensor([0.37], device='cuda'), torch.tensor([1.9], device='cuda')
+    d = hip.gemm_desc(hip.GEMM_TN, A.view(torch.uint8), B.view(torch.uint8), torch.empty(M, N, device='cuda'), M, N, K, M, N, N, fp8_format=afmt)
+    ws = torch.empty(max(lib().ecgvit_gemm_workspace(hip.byref(d)), 16), dtype=torch.uint8, device='cuda')
+    assert hip.gemm_kernel(hip.GEMM_TN, A.view(torch.uint8), B.view(torch.uint8), torch.empty(M, N, device='cuda'), M, N, K, M, N, N, fp8_format=afmt,
+                           workspace=ws) == hip.KERNEL_GEMM_WGRAD
+    C = torch.full((M, N), float('nan'), device='cuda')
+    hip.gemm(hip.GEMM_TN, A.view(torch.uint8), B.view(torch.uint8), C, M, N, K, M, N, N, fp8_format=afmt, scale_a=sa, scale_b=sb, workspace=ws)
+    ref = (A.float().t() @ B.float()) * (0.37 * 1.9)
+    assert torch.isfinite(C).all()
+    assert rel_err(C, ref) < 5e-5      # f32 summation order over up to 70 011 terms (the torch reference rounds too); exactness: below
+    Ai = torch.randint(-2, 3, (K, M), generator=g).float().to(FMT[afmt][0]).cuda()
+    Bi = torch.randint(-2, 3, (K, N), generator=g).float().to(torch.float8_e4m3fn).cuda()
+    one = torch.ones(1, device='cuda')
+    want = Ai.float().t() @ Bi.float()
+    for _ in range(3):
+        C.fill_(float('nan'))
+        hip.gemm(hip.GEMM_TN, Ai.view(torch.uint8), Bi.view(torch.uint8), C, M, N, K, M, N, N, fp8_format=afmt, scale_a=one, scale_b=one, workspace=ws)
+        assert torch.equal(C, want)
