@@ -181,8 +181,9 @@ class VitEngine:
             check(lib().ecgvit_fp8_scale_update(ptr(self.f8_scale), ptr(self.f8_amax), self.f8_scale.numel(), ptr(self.f8_fmt), 0, stream()),
                   'fp8_scale_update')
 
-    def _quant(self, site, x, count):
-        """x (bf16, `count` elements) -> the shared 8-bit scratch in the site's format; returns (scratch view, scale pointer tensor)"""
+    def _quant(self, site, x, count, out=None):
+        """x (bf16, `count` elements) -> `out` (a layer's persistent e4m3 copy: the weight-gradient product reads it again in the
+        backward pass) or the shared 8-bit scratch, in the site's format; returns (8-bit view, scale pointer tensor)"""
         l, st = lib(), stream()
         sc, am = self.f8_scale[site:site + 1], self.f8_amax[site:site + 1]
         fmt = hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2
@@ -190,32 +191,33 @@ class VitEngine:
             check(l.ecgvit_fp8_amax(ptr(x), None, 1, count, ptr(am), st), 'fp8_amax')
             check(l.ecgvit_fp8_scale_update(ptr(sc), ptr(am), 1, None, fmt, st), 'fp8_scale_update')
             self._f8_seen.add(site)
-        q = self.act['q8'][:count]
+        q = out if out is not None else self.act['q8'][:count]
         check(l.ecgvit_fp8_quantize(ptr(x), ptr(q), None, 1, count, fmt, ptr(sc), ptr(am), st), 'fp8_quantize')
         return q, sc
 
-    def _emit8(self, kw, site, ld):
+    def _emit8(self, kw, site, ld, out=None):
         """ask an 8-bit product's epilogue to also write the 8-bit copy of its output that the next product (site `site`) consumes --
-        possible once that site has a scale (from the second pass on); returns True when armed"""
+        possible once that site has a scale (from the second pass on); `out`: where (default: the q8b scratch); returns True when armed"""
         if site not in self._f8_seen:
             return False
         kw['epilogue'] = kw.get('epilogue', 0) | hip.EPI_QUANT_OUT
-        kw.update(q8_out=self.act['q8b'], ldq8=ld, q8_scale=self.f8_scale[site:site + 1], q8_amax=self.f8_amax[site:site + 1],
+        kw.update(q8_out=out if out is not None else self.act['q8b'], ldq8=ld, q8_scale=self.f8_scale[site:site + 1], q8_amax=self.f8_amax[site:site + 1],
                   q8_format=hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2)
         return True
 
-    def _linear(self, site, A, name, C, M, N, K, emit_site=None, prequant=False, **kw):
+    def _linear(self, site, A, name, C, M, N, K, a8=None, emit_site=None, emit_to=None, prequant=False, **kw):
         """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow.
-        emit_site: the site that consumes C next (its 8-bit copy is then written by this epilogue); prequant: A's copy is already in q8b.
-        Returns True when the 8-bit copy of C was emitted."""
+        a8: this layer's persistent e4m3 copy of A (written here, or already by A's producer when `prequant`; the weight-gradient
+        product of the backward pass reads it again); emit_site / emit_to: the site that consumes C next and its persistent copy
+        (then written by this epilogue).  Returns True when the 8-bit copy of C was emitted."""
         if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
             self._gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
             return False
-        if prequant:   # the producer already wrote A's 8-bit copy: 'q8' (LayerNorm) or q8b (a GEMM epilogue)
-            q, sc = self.act['q8' if prequant == 'q8' else 'q8b'][:M * K], self.f8_scale[site:site + 1]
+        if prequant:   # the producer (LayerNorm forward, a GEMM epilogue) already wrote A's 8-bit copy into a8
+            q, sc = a8, self.f8_scale[site:site + 1]
         else:
-            q, sc = self._quant(site, A, M * K)
-        emitted = emit_site is not None and self._emit8(kw, emit_site, N)
+            q, sc = self._quant(site, A, M * K, out=a8)
+        emitted = emit_site is not None and self._emit8(kw, emit_site, N, out=emit_to)
         mi = self.w8_index[name]
         self._gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
         return emitted
@@ -242,18 +244,23 @@ class VitEngine:
             return None, 0, 0
         return torch.tensor(rows_, dtype=torch.int64, device=device), len(rows_), t
 
-    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, prequant=False, **kw):
+    def _grad8(self, site, dY, count, prequant=False):
+        """(e5m2 copy of the gradient dY entering site `site`, its scale) for the site's two backward products -- the input gradient
+        dY . W and the weight gradient dY^T . X; prequant: its producer already wrote the copy ('q8': LayerNorm backward into the
+        operand scratch, True: a GEMM epilogue into q8b).  None when the 8-bit path does not apply."""
+        if prequant:
+            return self.act['q8' if prequant == 'q8' else 'q8b'][:count], self.f8_scale[site:site + 1]
+        return self._quant(site, dY, count)
+
+    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, pre=None, **kw):
         """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one.
-        Returns True when the 8-bit copy of dX was emitted for `emit_site` (fp8_linear)."""
-        if self.fp8 and site is not None and M >= 2048 and name in self.w8_index:
-            if prequant:   # the producer already wrote dY's 8-bit copy: 'q8' (LayerNorm backward) or q8b (a GEMM epilogue)
-                q, sc = self.act['q8' if prequant == 'q8' else 'q8b'][:M * nout], self.f8_scale[site:site + 1]
-            else:
-                q, sc = self._quant(site, dY, M * nout)
+        pre: (8-bit copy of dY, scale) from `_grad8` (fp8_linear).  Returns True when the 8-bit copy of dX was emitted for `emit_site`."""
+        if self.fp8 and pre is not None and name in self.w8_index:
+            q, sc = pre
             emitted = emit_site is not None and self._emit8(kw, emit_site, kin)
             mi = self.w8_index[name]
             self._gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
-                     scale_b=self.w8_scale[mi:mi + 1], **kw)
+                       scale_b=self.w8_scale[mi:mi + 1], **kw)
             return emitted
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
@@ -281,6 +288,10 @@ class VitEngine:
                 l['probs'] = e(B * h * N * N)
             else:
                 l['lse'] = e(B * h * N, dt=torch.float32)
+            if self.fp8 and M >= 2048:
+                # e4m3 copies of the four Linear inputs, kept for the backward pass: the 8-bit weight-gradient products read them again
+                # (one byte per element next to the two of the bf16 tensors: +0.9 GB per layer for large at 256 x 501 tokens)
+                l.update(xn1_8=e(M * d, dt=torch.uint8), attn_8=e(M * d, dt=torch.uint8), xn2_8=e(M * d, dt=torch.uint8), hact_8=e(M * f, dt=torch.uint8))
             L.append(l)
         a['layers'] = L
         a.update(logits=e(B, self.K, dt=torch.float32), xhat=e(B, d, dt=torch.float32), hrstd=e(B, dt=torch.float32),
@@ -307,13 +318,13 @@ class VitEngine:
         self.act, self.B = a, B
 
     # ---------------------------------------------------------------- small launch helpers
-    def _ln_fwd(self, x, g, b, y, mean, rstd, rows, q8_site=None):
+    def _ln_fwd(self, x, g, b, y, mean, rstd, rows, q8_site=None, y8=None):
         """LayerNorm forward; q8_site (fp8_linear): also write the e4m3 copy of y into the operand scratch for the Linear that consumes
         it (returns True), once that site has a scale and when the exact-fit kernel covers d"""
         d = self.d
         if (self.fp8 and q8_site is not None and q8_site in self._f8_seen and rows >= 2048 and d % 256 == 0
                 and d // 64 in (4, 8, 12, 16, 24, 32)):
-            check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS, ptr(self.act['q8']),
+            check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS, ptr(y8 if y8 is not None else self.act['q8']),
                                                 ptr(self.f8_scale[q8_site:q8_site + 1]), ptr(self.f8_amax[q8_site:q8_site + 1]), stream()),
                   'layernorm_fwd_q8')
             return True
@@ -348,8 +359,15 @@ class VitEngine:
     def _drop_apply(self, src, dst, count, p, seed):
         check(lib().ecgvit_dropout_apply(ptr(src), ptr(dst), count, p, seed, hip.code(self.dtype), stream()), 'dropout_apply')
 
-    def _wgrad(self, dY, X, name, Mout, Nin, rows):
-        """dW[Mout, Nin] = dY[rows, Mout]^T . X[rows, Nin]  -> f32 gradient view (overwritten)"""
+    def _wgrad(self, dY, X, name, Mout, Nin, rows, pre=None, x8=None, xsite=None):
+        """dW[Mout, Nin] = dY[rows, Mout]^T . X[rows, Nin]  -> f32 gradient view (overwritten).  fp8_linear: pre = (e5m2 copy of dY,
+        scale) from `_grad8`, x8 / xsite = the layer's persistent e4m3 copy of X and its site (scale): the product then runs on the
+        8-bit streaming kernel (both operands k-major, transposed 8-bit LDS reads)"""
+        if pre is not None and x8 is not None and Mout % 256 == 0 and Nin % 256 == 0 and rows >= 4096:
+            q, sc = pre
+            self._gemm(GEMM_TN, q, x8, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'], fp8_format=hip.BF8_E5M2,
+                       scale_a=sc, scale_b=self.f8_scale[xsite:xsite + 1])
+            return
         self._gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
 
     # ---------------------------------------------------------------- forward
@@ -383,28 +401,30 @@ class VitEngine:
             lp = f'{pre}transformer.layers.{i}.'
             s0 = seed + 100 * (i + 1)
             # a6/a7: PreNorm(Attention)
-            q1 = self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M, q8_site=8 * i)
-            self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d, prequant='q8' if q1 else False)
+            f8 = self.fp8 and M >= 2048
+            q1 = self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M, q8_site=8 * i,
+                              y8=L.get('xn1_8'))
+            self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d, a8=L.get('xn1_8'), prequant=q1)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
                                              T, st), 'attention_fwd')
             else:
                 self._attn_fwd_f32(L, B, ph, s0 + 1)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, epilogue=epi,
-                     bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
+            self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, a8=L.get('attn_8'), epilogue=epi,
+                         bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
             # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
             q2 = self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M,
-                              q8_site=8 * i + 2)
+                              q8_site=8 * i + 2, y8=L.get('xn2_8'))
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
-            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, emit_site=8 * i + 3, prequant='q8' if q2 else False,
-                              epilogue=epi,
+            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, a8=L.get('xn2_8'), emit_site=8 * i + 3,
+                              emit_to=L.get('hact_8'), prequant=q2, epilogue=epi,
                               bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, prequant=hq, epilogue=epi,
-                     bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
+            self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, a8=L.get('hact_8'), prequant=hq, epilogue=epi,
+                         bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)
             X = L['x2']
         return X
 
@@ -620,17 +640,20 @@ class VitEngine:
                     self._drop_apply(dX, a['dxm'], M * d, ph, s0 + 4)
                     dY = a['dxm']
                 self._colsum(dY, d, G[lp + '1.fn.net.3.bias'], M, d)
-            self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M)
+            f8 = self.fp8 and M >= 2048
+            g4 = self._grad8(8 * i + 4, dY, M * d, prequant='q8' if pq4 else False) if f8 else None
+            self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M, pre=g4, x8=L.get('hact_8'), xsite=8 * i + 3)
             # dgrad with GELU' (+ dropout mask) epilogue; the epilogue also reduces the columns = gradient of the FFN-up bias
             if self.dtype == torch.bfloat16:
                 epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
-            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, prequant='q8' if pq4 else False,
+            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, pre=g4,
                              epilogue=epi, aux=L['hpre'],
                              ldaux=f, dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
-            self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M)
-            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5, prequant=bool(dq))
+            g5 = self._grad8(8 * i + 5, a['dh'], M * f, prequant=bool(dq)) if f8 else None
+            self._wgrad(a['dh'], L['xn2'], lp + '1.fn.net.0.weight', f, d, M, pre=g5, x8=L.get('xn2_8'), xsite=8 * i + 2)
+            self._dgrad(a['dh'], lp + '1.fn.net.0.weight', a['dxn'], M, d, f, site=8 * i + 5, pre=g5)
             # LN2 backward; its output feeds the attention out-projection site (mask seed s0+2, bias to_out.0.bias)
             pq6 = self._ln_bwd_fused(a['dxn'], L['x1'], self.P32[lp + '1.norm.weight'], L['mean2'], L['rstd2'], dX, other,
                                      G[lp + '1.norm.weight'], G[lp + '1.norm.bias'], M, a['dxm'], G[lp + '0.fn.to_out.0.bias'], ph, s0 + 2,
@@ -638,15 +661,17 @@ class VitEngine:
             dX, other = other, dX  # dX = d(x1)
             dY = a['dxm'] if ph > 0 else dX
             # ---- Attention backward: x1 = drop(attn Wo^T + bo) + x
-            self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M)
-            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6, prequant='q8' if pq6 else False)
+            g6 = self._grad8(8 * i + 6, dY, M * d, prequant='q8' if pq6 else False) if f8 else None
+            self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M, pre=g6, x8=L.get('attn_8'), xsite=8 * i + 1)
+            self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6, pre=g6)
             if self.dtype == torch.bfloat16:
                 check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
                                              dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
             else:
                 self._attn_bwd_f32(L, B, ph, s0 + 1)
-            self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M)
-            self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d, site=8 * i + 7)
+            g7 = self._grad8(8 * i + 7, a['dqkv'], M * 3 * d) if f8 else None
+            self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M, pre=g7, x8=L.get('xn1_8'), xsite=8 * i)
+            self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d, site=8 * i + 7, pre=g7)
             if i > 0:
                 # LN1 backward; its output feeds layer i-1's FFN-down site (mask seed of layer i-1, bias net.3.bias)
                 lq = f'{pre}transformer.layers.{i - 1}.'

@@ -147,8 +147,8 @@ def test_model_fp8_linear_vs_bf16_path():
 
 def test_fp8_large_layer_shape_vs_cpu_oracle():
     """The fp8 Linear path against the CPU ORACLE (torch eager f32 restatement of the reference step), not against another HIP path:
-    EcgVit-large layer shape (d = 1024, 16 heads, ffn 4096), patch 10 -> 501 tokens, 2 layers, 5 records (2 505 token rows: above the
-    8-bit kernel's 2 048-row floor), dropout 0.  Tolerances (written here, BASELINE.json configs[4]): e4m3 operands carry 3 mantissa
+    EcgVit-large layer shape (d = 1024, 16 heads, ffn 4096), patch 10 -> 501 tokens, 2 layers, 9 records (4 509 token rows: above the
+    8-bit products' 2 048-row floor and the 8-bit weight-gradient kernel's 4 096-row floor), dropout 0.  Tolerances (written here, BASELINE.json configs[4]): e4m3 operands carry 3 mantissa
     bits (2^-4 relative per element, averaged down by the K = 1024 .. 4096 sums), e5m2 gradients 2 bits; the loss must sit within 3 %
     of the oracle's, the logits within 0.2 absolute, the whole gradient at cosine >= 0.97 and every parameter tensor at >= 0.90."""
     from oracle import vit_oracle as O
@@ -160,12 +160,22 @@ def test_fp8_large_layer_shape_vs_cpu_oracle():
     m8 = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True)
     m8.load_state_dict(ref.state_dict())
     m8.cuda().train()
-    x, y = O.synthetic_batch(5, length=5000, seed=77)
+    x, y = O.synthetic_batch(9, length=5000, seed=77)
     o_ref = ref(sample_values=x, labels=y)
     o_ref.loss.backward()
-    o8 = m8(sample_values=x.cuda(), labels=y.cuda())
-    o8.loss.backward()
+    kinds, real = [], hip.gemm
+
+    def spy(layout, *a, **k):
+        kinds.append((layout, k.get('fp8_format')))
+        return real(layout, *a, **k)
+    hip.gemm = spy
+    try:
+        o8 = m8(sample_values=x.cuda(), labels=y.cuda())
+        o8.loss.backward()
+    finally:
+        hip.gemm = real
     assert len(m8._engine()._f8_seen) == 16, 'the 8-bit Linear path did not run'         # 8 sites x 2 layers
+    assert kinds.count((hip.GEMM_TN, hip.BF8_E5M2)) == 8, kinds                           # the 4 weight gradients of both layers ran on 8-bit operands
     lref = float(o_ref.loss.detach())
     assert abs(float(o8.loss.detach()) - lref) / lref < 3e-2, (float(o8.loss.detach()), lref)
     assert float((o8.logits.detach().cpu() - o_ref.logits.detach()).abs().max()) < 0.2
