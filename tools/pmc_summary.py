@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 def family(n):
     if 'gemm_nt_kernel' in n: return 'gemm_nt'           # dominant symbol: persistent A.B^T GEMM (forward + input gradients)
+    if 'gemm_wgrad8_kernel' in n: return 'gemm_wgrad8'   # the same on 8-bit operands (fp8_linear)
     if 'gemm_wgrad_kernel' in n: return 'gemm_wgrad'     # streaming weight-gradient GEMM
     if 'splitk_reduce' in n: return 'splitk_reduce'
     if 'gemm_bf16_kernel' in n: return 'gemm_128'        # small / ragged products
