@@ -478,6 +478,7 @@ template <int OFF> __device__ __forceinline__ bf16x4 tr_read_asm_o(uint32_t lds_
 }
 // two f32 -> one dword of two bf16 (v_cvt_pk_bf16_f32): explicit pairs, so every accumulator value is converted exactly once
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     f32x2_t v; v[0] = a; v[1] = b;
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -636,9 +637,26 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         // W: dS -> LDS | wait + barrier | C: dQ tile (8 small MFMA) + store.  Block j lives in ring slot (slot0 + j) & 3 and uses
         // delta / dS buffer (jj0 + j) & 1.
         const int slot0 = slot, jj0 = jj;
+        [[maybe_unused]] i32x4_t rdq_words;   // ACCUM: the dQ descriptor of this item as four dwords (operand of the inline-asm load)
+        {
+            const uintptr_t pa = reinterpret_cast<uintptr_t>(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64);
+            rdq_words = i32x4_t{(int)(uint32_t)pa, (int)((pa >> 32) & 0xFFFFu), (int)bytes_q, 0x00020000};
+        }
         f32x16 s, dp;            // scores / dP accumulators of the block whose A phase ran last
         uint32_t Pk[8], Dk[8];   // bf16 pairs (2m, 2m+1) of P (dropped) and dS: MFMA B operands AND the dS^T image rows
+        // ACCUM (second key window): the first window's dQ values this wave adds to are requested at the TOP of the block, by inline asm --
+        // a builtin load behind LDS-DMA pieces is waited for with vmcnt(0) by hipcc (it does not model the pieces), draining the stream
+        // once per block (+15 % kernel time).  Older than everything else the block issues, the request is retired by the block's one
+        // counted wait; the value is consumed behind that block's barrier (C phase).
+        // (The trailing group consumes block j's value one block later than it requests block j+1's: two register pairs, moved, never indexed.)
+        u32x2 dq_prev = {0u, 0u}, dq_req = {0u, 0u};
         auto ph_issue = [&](int qb) __attribute__((always_inline)) {
+            if constexpr (ACCUM) {
+                const int qt = wave & 1, dhc = wave >> 1;
+                const uint32_t off = (uint32_t)(((qb * 32 + qt * 16 + dq_i) * d3 + dhc * 16 + 4 * dq_g) * 2);
+                dq_prev = dq_req;   // block qb-1's value (landed: the previous block's counted wait covered it)
+                asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dq_req) : "v"(off), "s"(rdq_words) : "memory");
+            }
             const int sl = (slot0 + qb) & 3;
             // ---- feed the stream: next item's K / V / LSE once, slab qb+3 (of this item or the first slabs of the next)
             if (has_next && qb == 1) {
@@ -745,13 +763,19 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             if (!has_next) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else if (late) {
-                if (qb == 0) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+                // (ACCUM, first block of an item: the dQ request is YOUNGER than the previous item's 8 dK / dV stores: they must retire too)
+                if (qb == 0) { if (ACCUM) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); }
                 else if (qb == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-            } else {
+            } else if (!ACCUM) {
                 if (qb == 0) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
                 else if (qb == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+            } else {
+                // ACCUM: this block's dQ request sits between the previous dQ store and the slab pieces: it must have landed too
+                if (qb == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");    // behind the previous item's 8 dK / dV stores: see above
+                else if (qb == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
             }
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 9 + qb] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
@@ -761,7 +785,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             if (has_next && qb == nqb - 1) load_v(nxt, vfn);
         };
         // ---- dQ tile of this wave (one 16 x 16 tile: qt = wave&1, dhc = wave>>1), then its store
-        auto ph_C = [&](int qb) __attribute__((always_inline)) {
+        auto ph_C = [&](int qb, bool use_prev = false) __attribute__((always_inline)) {
             const char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
             const int qt = wave & 1, dhc = wave >> 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -786,8 +810,10 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
             const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
-            if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16)
-                const bf16x4 o = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0));
+            if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16; requested in ph_issue of this block)
+                // leading group and the item's last block: C(qb) runs behind the barrier of the block that requested it (dq_req);
+                // trailing group otherwise: one block later, after the next request went out (dq_prev)
+                const bf16x4 o = __builtin_bit_cast(bf16x4, use_prev ? dq_prev : dq_req);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
             }
@@ -834,7 +860,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 ph_W(qb);
                 ph_B(qb);
                 PH_STAMP(qb, 4);
-                ph_C(qb - 1);
+                ph_C(qb - 1, true);
                 PH_STAMP(qb, 5);
                 ph_A(qb + 1);
                 PH_STAMP(qb, 2);
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             ph_V(nqb - 1);
             ph_W(nqb - 1);
             ph_B(nqb - 1);
-            ph_C(nqb - 2);
+            ph_C(nqb - 2, true);
             ph_waitbar(nqb - 1);
             ph_C(nqb - 1);
         }
