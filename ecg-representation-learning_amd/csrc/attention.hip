@@ -132,10 +132,14 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
 // =====================================================================================================
 // forward: online softmax over 32-key tiles (running max / sum per query, O rescaled when the max moves)
 // =====================================================================================================
-template <bool DROP>
+// Q8 (fp8_linear): additionally out8 = saturate(out as stored / *q8_scale) in e4m3 -- the A operand of the out-projection's 8-bit
+// product, written here instead of by a quantise pass over `out` -- and *q8_amax = max(*q8_amax, max |out|) for the next step's scale
+template <bool DROP, bool Q8 = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                float *__restrict__ lse, int N, int h, float scale,
-                                                               uint64_t seed, uint32_t thresh, float inv_keep) {
+                                                               uint64_t seed, uint32_t thresh, float inv_keep,
+                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                               float *__restrict__ q8_amax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nkt = (N + 31) >> 5, NK = nkt * 32;
     char *Kimg = smem, *Vimg = smem + NK * 128;
@@ -224,9 +228,12 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             }
         }
         l += __shfl_xor(l, 32, 64);
+        [[maybe_unused]] float qmax = 0.f;
         if (q < N) {
             const float inv = inv_keep / l;   // inv_keep = 1 without dropout
             bf16_t *orow = out + ((int64_t)b * N + q) * d + hd * 64;
+            [[maybe_unused]] float q8_inv = 0.f;
+            if constexpr (Q8) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -235,8 +242,25 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
                     *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * g4 + 4 * lh) = v;
+                    if constexpr (Q8) {
+                        float f[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            f[k] = (float)v[k];                       // the value as stored
+                            qmax = fmaxf(qmax, fabsf(f[k]));
+                            f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -448.f, 448.f);
+                        }
+                        int w = 0;
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+                        *reinterpret_cast<uint32_t *>(out8 + ((int64_t)b * N + q) * d + hd * 64 + dt * 32 + 8 * g4 + 4 * lh) = (uint32_t)w;
+                    }
                 }
             if (lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
+        }
+        if constexpr (Q8) {
+            qmax = wave_max(qmax);
+            if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
         }
     }
 }
@@ -488,11 +512,20 @@ __device__ __forceinline__ uint32_t lds_addr_of(const char *p) { return (uint32_
 // Records longer than 256 tokens (N <= 512, e.g. patch 10 -> 501) run as TWO launches, one per half of the keys: `k0` is the first key
 // of this launch's 256-key window, queries always run over all of N; the second launch adds its dQ to the first one's (ACCUM).
 // PRIO: static wave priority for the whole kernel (no per-phase flips): 0 none, 1 waves 4-7 raised, 2 waves 0-3 raised
-template <bool DROP, bool ACCUM, bool STAGGER = true, int PRIO = 1>
+// Q8 (fp8_linear; bit 0: dK / dV, bit 1: dQ): additionally dqkv8 = saturate(dqkv as stored / *q8_scale) in e5m2 (same [B*N, 3*h*dh] layout, one
+// byte per element) -- the A operand of the QKV projection's two backward products, written here instead of by a quantise pass over
+// dqkv -- and *q8_amax = max(*q8_amax, max |dqkv|).  With two key windows the first launch emits its dK / dV only (dQ is final in the second).
+template <bool DROP, bool ACCUM, bool STAGGER = true, int PRIO = 1, int Q8 = 0>
 __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                             const bf16_t *__restrict__ dout, const float *__restrict__ lse,
                                                             bf16_t *__restrict__ dqkv, int N, int h, float scale, uint64_t seed,
-                                                            uint32_t thresh, float inv_keep, int nitems, int k0) {
+                                                            uint32_t thresh, float inv_keep, int nitems, int k0,
+                                                            uint8_t *__restrict__ dqkv8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                            float *__restrict__ q8_amax = nullptr) {
+    constexpr int SQ = (Q8 & 2) ? 2 : 1;     // stores of one dQ tile (C phase)
+    constexpr int SF = (Q8 & 1) ? 16 : 8;    // dK / dV stores of one item's flush
+    [[maybe_unused]] float q8_inv = 0.f, qmax = 0.f;
+    if constexpr (Q8 != 0) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
     constexpr int NKT = 8, NK = 256, NQ = 512, IMG = 32768, DSB = 16384, SLAB = 12288;
     __shared__ __attribute__((aligned(1024))) char smem[2 * IMG + 4 * SLAB + 2 * DSB + 2 * NQ * 4 + 2 * 32 * 4];
     char *const Kimg0 = smem, *const slab0 = smem + 2 * IMG, *const dSimg = slab0 + 4 * SLAB;
@@ -760,23 +793,30 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         auto ph_waitbar = [&](int qb) __attribute__((always_inline)) {
             __builtin_amdgcn_sched_barrier(0);
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 1 + qb] = __builtin_amdgcn_s_memtime();
+            // allowed in flight (youngest first), with SQ = stores of a dQ tile and SF = dK / dV stores of an item's flush:
+            //   leading:  this block's 2 slab pieces [+ K / LSE prefetch 5 at qb == 1] + the previous dQ tile's SQ stores [qb == 0: + SF + SQ of the previous item]
+            //   trailing: 1 slab piece [+ 5] + SQ [qb == 0: + SF + SQ]
+            //   ACCUM: this block's dQ request is OLDER than its pieces and must have landed: leading 2 [+ 5]; trailing 1 + SQ [+ 5]; on an
+            //   item's first block it is YOUNGER than the previous item's stores: 2 / 1
+#define ATTN_WAIT(N_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory")
             if (!has_next) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             } else if (late) {
-                // (ACCUM, first block of an item: the dQ request is YOUNGER than the previous item's 8 dK / dV stores: they must retire too)
-                if (qb == 0) { if (ACCUM) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory"); }
-                else if (qb == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                // (lockstep order: the trailing waves' dQ stores of the previous block are OLDER than this block's request)
+                constexpr int SQL = (ACCUM && !STAGGER) ? 0 : SQ;
+                if (qb == 0) { if (ACCUM) ATTN_WAIT(1); else ATTN_WAIT(1 + SF + SQ); }
+                else if (qb == 1) ATTN_WAIT(6 + SQL);
+                else ATTN_WAIT(1 + SQL);
             } else if (!ACCUM) {
-                if (qb == 0) asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
-                else if (qb == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                if (qb == 0) ATTN_WAIT(2 + SF + SQ);
+                else if (qb == 1) ATTN_WAIT(7 + SQ);
+                else ATTN_WAIT(2 + SQ);
             } else {
-                // ACCUM: this block's dQ request sits between the previous dQ store and the slab pieces: it must have landed too
-                if (qb == 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");    // behind the previous item's 8 dK / dV stores: see above
-                else if (qb == 1) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                if (qb == 0) ATTN_WAIT(2);
+                else if (qb == 1) ATTN_WAIT(7);
+                else ATTN_WAIT(2);
             }
+#undef ATTN_WAIT
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 9 + qb] = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_barrier();
             if (stamps && threadIdx.x == 0 && item_no < 4 && qb < 8) stamps[item_no * 32 + 17 + qb] = __builtin_amdgcn_s_memtime();
@@ -818,6 +858,20 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
+            if constexpr ((Q8 & 2) != 0) {
+                float f[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = (float)v[r];                            // the value as stored
+                    qmax = fmaxf(qmax, q < N ? fabsf(f[r]) : 0.f);
+                    f[r] = __builtin_amdgcn_fmed3f(f[r] * q8_inv, -57344.f, 57344.f);
+                }
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w, false);
+                w = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w, true);
+                const __amdgpu_buffer_rsrc_t rdq8 = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv8 + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q / 2, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(w, rdq8, q * d3 + dhc * 16 + 4 * dq_g, 0, 0);
+            }
         };
         // The two waves of a SIMD (w and w + 4) would run the same phases between the same barriers -- MFMA phases together, VALU
         // phases together (22 % MFMA-busy, 43 % of wave time waiting).  Waves 4-7 run HALF A BLOCK LATE instead: between two
@@ -903,6 +957,24 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                     const u32x4 val = *reinterpret_cast<const u32x4 *>(patch + img_off(row, ch * 16));
                     const __amdgpu_buffer_rsrc_t rkv = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + ((int64_t)cur.b * N + k0) * d3 + (1 + which) * d + cur.hd * 64), 0, bytes_k, 0x00020000);
                     __builtin_amdgcn_raw_buffer_store_b128(val, rkv, (key * d3 + ch * 8) * 2, 0, 0);   // keys >= N: dropped
+                    if constexpr ((Q8 & 1) != 0) {
+                        float f[8];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { f[2 * k] = __builtin_bit_cast(float, val[k] << 16); f[2 * k + 1] = __builtin_bit_cast(float, val[k] & 0xFFFF0000u); }
+                        const bool kin = key + k0 < N;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            qmax = fmaxf(qmax, kin ? fabsf(f[k]) : 0.f);
+                            f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -57344.f, 57344.f);
+                        }
+                        int w0 = 0, w1 = 0;
+                        w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], w0, true);
+                        w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], w1, true);
+                        u32x2 q2;
+                        q2[0] = (uint32_t)w0; q2[1] = (uint32_t)w1;
+                        const __amdgpu_buffer_rsrc_t rkv8 = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv8 + ((int64_t)cur.b * N + k0) * d3 + (1 + which) * d + cur.hd * 64), 0, bytes_k / 2, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b64(q2, rkv8, key * d3 + ch * 8, 0, 0);
+                    }
                 }
             }
         }
@@ -918,6 +990,10 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         par ^= 1;
         it = next_it;
         cur = nxt;
+    }
+    if constexpr (Q8 != 0) {   // one atomic max per wave and launch (non-negative floats order as integers)
+        qmax = wave_max(qmax);
+        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
     }
 }
 
@@ -1008,10 +1084,11 @@ int ecgvit_attention_probs(const void *qkv, const float *lse, float *probs, int 
     return ECGVIT_OK;
 }
 
-int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
-                         uint64_t seed, int dtype, void *stream) {
+static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
+                                uint64_t seed, int dtype, void *stream, void *out8, const float *q8_scale, float *q8_amax) {
     if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) % 16) return ECGVIT_EINVAL;
+    if (out8 && (!q8_scale || !q8_amax || reinterpret_cast<uintptr_t>(out8) % 4)) return ECGVIT_EINVAL;
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
@@ -1021,12 +1098,27 @@ int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, i
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
         if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
+        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
+        if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
         attr_set = true;
     }
-    if (th) hipLaunchKernelGGL(attn_fwd_bf16_kernel<true>, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
-    else hipLaunchKernelGGL(attn_fwd_bf16_kernel<false>, grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik);
+#define FWD(DR, Q) hipLaunchKernelGGL((attn_fwd_bf16_kernel<DR, Q>), grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, (uint8_t *)out8, q8_scale, q8_amax)
+    if (out8) { if (th) FWD(true, true); else FWD(false, true); }
+    else { if (th) FWD(true, false); else FWD(false, false); }
+#undef FWD
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
+}
+
+int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
+                         uint64_t seed, int dtype, void *stream) {
+    return attention_fwd_launch(qkv, out, lse, B, N, h, dh, scale, dropout_p, seed, dtype, stream, nullptr, nullptr, nullptr);
+}
+
+int ecgvit_attention_fwd_q8(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
+                            uint64_t seed, void *out8, const float *q8_scale, float *q8_amax, void *stream) {
+    if (!out8) return ECGVIT_EINVAL;
+    return attention_fwd_launch(qkv, out, lse, B, N, h, dh, scale, dropout_p, seed, ECGVIT_BF16, stream, out8, q8_scale, q8_amax);
 }
 
 static int attention_bwd_args_ok(const void *qkv, const void *out, const void *dout, void *dqkv, int B, int N, int h, int dh, int dtype) {
@@ -1051,11 +1143,15 @@ int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *d
     return ECGVIT_OK;
 }
 
-int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
-                         int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+static int attention_bwd_launch(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                                int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream, void *dqkv8, const float *q8_scale,
+                                float *q8_amax) {
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype)) return ECGVIT_EINVAL;
-    if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31))   // short sequences / 32-bit buffer offsets exhausted
+    if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31)) {   // short sequences / 32-bit buffer offsets exhausted
+        if (dqkv8) return ECGVIT_EINVAL;   // the one-item kernel has no 8-bit emission: the caller quantises dqkv itself
         return ecgvit_attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
+    }
+    if (dqkv8 && (!q8_scale || !q8_amax || reinterpret_cast<uintptr_t>(dqkv8) % 8)) return ECGVIT_EINVAL;
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
@@ -1065,8 +1161,10 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
     const dim3 pg((unsigned)(nitems < 768 ? nitems : 768));
 #define PERS_ARGS(K0) pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0
 #define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), PERS_ARGS(K0))
+// (the emitting variants run the lockstep schedule: the staggered one has no registers left for the conversions -- 256 VGPRs + spills)
+#define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, false, 1, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
-    if (g_tools_attn_variant >= 0 && th && N <= 256) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)
+    if (g_tools_attn_variant >= 0 && th && N <= 256 && !dqkv8) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)
         switch (g_tools_attn_variant) {
             case 0: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 1>), PERS_ARGS(0)); break;   // round-2 kernel
             case 1: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 0>), PERS_ARGS(0)); break;
@@ -1079,6 +1177,17 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
         return ECGVIT_OK;
     }
 #endif
+    if (dqkv8) {
+        // one window: dK / dV / dQ all final in this launch; two windows: the first emits its dK / dV, the second its dK / dV and the final dQ
+        if (N <= 256) { if (th) PERS8(true, false, 0, 3); else PERS8(false, false, 0, 3); }
+        else { if (th) PERS8(true, false, 0, 1); else PERS8(false, false, 0, 1); }
+        ECGVIT_CHECK_LAUNCH();
+        if (N > 256) {
+            if (th) PERS8(true, true, 256, 3); else PERS8(false, true, 256, 3);
+            ECGVIT_CHECK_LAUNCH();
+        }
+        return ECGVIT_OK;
+    }
     if (th) PERS(true, false, 0); else PERS(false, false, 0);
     ECGVIT_CHECK_LAUNCH();
     if (N > 256) {   // second window of keys; its dQ accumulates on the first launch's (stream order)
@@ -1086,7 +1195,19 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
         ECGVIT_CHECK_LAUNCH();
     }
 #undef PERS
+#undef PERS8
     return ECGVIT_OK;
+}
+
+int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                         int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    return attention_bwd_launch(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream, nullptr, nullptr, nullptr);
+}
+
+int ecgvit_attention_bwd_q8(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                            int dh, float scale, float dropout_p, uint64_t seed, void *dqkv8, const float *q8_scale, float *q8_amax, void *stream) {
+    if (!dqkv8) return ECGVIT_EINVAL;
+    return attention_bwd_launch(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, ECGVIT_BF16, stream, dqkv8, q8_scale, q8_amax);
 }
 
 int ecgvit_probe_mfma_layout(float *out, void *stream) {

@@ -405,13 +405,19 @@ class VitEngine:
             q1 = self._ln_fwd(X, self.P32[lp + '0.norm.weight'], self.P32[lp + '0.norm.bias'], L['xn1'], L['mean1'], L['rstd1'], M, q8_site=8 * i,
                               y8=L.get('xn1_8'))
             self._linear(8 * i + 0, L['xn1'], lp + '0.fn.to_qkv.weight', L['qkv'], M, 3 * d, d, a8=L.get('xn1_8'), prequant=q1)
+            qa = False   # fp8_linear: the attention kernel wrote the e4m3 copy of its output itself
             if self.dtype == torch.bfloat16:
-                check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
-                                             T, st), 'attention_fwd')
+                if f8 and (8 * i + 1) in self._f8_seen:
+                    check(l.ecgvit_attention_fwd_q8(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1, ptr(L['attn_8']),
+                                                    ptr(self.f8_scale[8 * i + 1:8 * i + 2]), ptr(self.f8_amax[8 * i + 1:8 * i + 2]), st), 'attention_fwd_q8')
+                    qa = True
+                else:
+                    check(l.ecgvit_attention_fwd(ptr(L['qkv']), ptr(L['attn']), ptr(L['lse']), B, N, h, dh, self.scale, ph, s0 + 1,
+                                                 T, st), 'attention_fwd')
             else:
                 self._attn_fwd_f32(L, B, ph, s0 + 1)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
-            self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, a8=L.get('attn_8'), epilogue=epi,
+            self._linear(8 * i + 1, L['attn'], lp + '0.fn.to_out.0.weight', L['x1'], M, d, d, a8=L.get('attn_8'), prequant=qa, epilogue=epi,
                          bias=self.P32[lp + '0.fn.to_out.0.bias'], residual=X, ldr=d, dropout_p=ph, seed=s0 + 2)
             # a6/a8: PreNorm(FeedForward): Linear -> GELU(erf) -> Dropout -> Linear -> Dropout, + residual
             q2 = self._ln_fwd(L['x1'], self.P32[lp + '1.norm.weight'], self.P32[lp + '1.norm.bias'], L['xn2'], L['mean2'], L['rstd2'], M,
@@ -664,12 +670,19 @@ class VitEngine:
             g6 = self._grad8(8 * i + 6, dY, M * d, prequant='q8' if pq6 else False) if f8 else None
             self._wgrad(dY, L['attn'], lp + '0.fn.to_out.0.weight', d, d, M, pre=g6, x8=L.get('attn_8'), xsite=8 * i + 1)
             self._dgrad(dY, lp + '0.fn.to_out.0.weight', a['dattn'], M, d, d, site=8 * i + 6, pre=g6)
+            pq7 = False   # fp8_linear: the attention backward wrote the e5m2 copy of dqkv itself (into the operand scratch)
             if self.dtype == torch.bfloat16:
-                check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
-                                             dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
+                if f8 and (8 * i + 7) in self._f8_seen and 128 < N <= 512 and N * 3 * d * 2 < 2 ** 31:
+                    check(l.ecgvit_attention_bwd_q8(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h, dh, self.scale,
+                                                    ph, s0 + 1, ptr(a['q8']), ptr(self.f8_scale[8 * i + 7:8 * i + 8]), ptr(self.f8_amax[8 * i + 7:8 * i + 8]), st),
+                          'attention_bwd_q8')
+                    pq7 = True
+                else:
+                    check(l.ecgvit_attention_bwd(ptr(L['qkv']), ptr(L['attn']), ptr(a['dattn']), ptr(L['lse']), ptr(a['dqkv']), B, N, h,
+                                                 dh, self.scale, ph, s0 + 1, T, st), 'attention_bwd')
             else:
                 self._attn_bwd_f32(L, B, ph, s0 + 1)
-            g7 = self._grad8(8 * i + 7, a['dqkv'], M * 3 * d) if f8 else None
+            g7 = self._grad8(8 * i + 7, a['dqkv'], M * 3 * d, prequant='q8' if pq7 else False) if f8 else None
             self._wgrad(a['dqkv'], L['xn1'], lp + '0.fn.to_qkv.weight', 3 * d, d, M, pre=g7, x8=L.get('xn1_8'), xsite=8 * i)
             self._dgrad(a['dqkv'], lp + '0.fn.to_qkv.weight', a['dxn'], M, d, 3 * d, site=8 * i + 7, pre=g7)
             if i > 0:

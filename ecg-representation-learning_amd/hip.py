@@ -68,7 +68,9 @@ SIGNATURES = {
     'ecgvit_colsum_workspace': (c_int64, [_L, _I]),
     'ecgvit_colsum': (c_int, [_P, _L, _P, _P, _L, _I, _I, _P]),
     'ecgvit_attention_fwd': (c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _I, _P]),
+    'ecgvit_attention_fwd_q8': (c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P, _P, _P]),
     'ecgvit_attention_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _I, _P]),
+    'ecgvit_attention_bwd_q8': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P, _P, _P]),
     'ecgvit_attention_bwd_oneitem': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _I, _P]),
     'ecgvit_attention_probs': (c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'ecgvit_softmax_rows': (c_int, [_P, _L, _I, _L, _P]),

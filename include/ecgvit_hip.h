@@ -200,9 +200,19 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale,
                          float dropout_p, uint64_t seed, int dtype, void *stream);
+/* fp8 operand path: the same forward that also writes out8 = saturate(out as stored / *q8_scale) in e4m3 (same [B*N, h*dh] layout, one byte
+ * per element) and accumulates *q8_amax = max(*q8_amax, max |out|): the 8-bit operand of the out-projection's product, without a quantise pass */
+int ecgvit_attention_fwd_q8(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
+                            uint64_t seed, void *out8, const float *q8_scale, float *q8_amax, void *stream);
 int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
                          int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
                          void *stream);
+/* fp8 operand path (128 < N <= 512 only: ECGVIT_EINVAL otherwise, the caller then quantises dqkv itself): the same backward that also writes
+ * dqkv8 = saturate(dqkv as stored / *q8_scale) in e5m2 (same [B*N, 3*h*dh] layout, one byte per element) and accumulates
+ * *q8_amax = max(*q8_amax, max |dqkv|): the 8-bit operand of the QKV projection's two backward products, without a quantise pass */
+int ecgvit_attention_bwd_q8(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
+                            int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, void *dqkv8,
+                            const float *q8_scale, float *q8_amax, void *stream);
 /* The same backward on the one-(record, head)-per-workgroup kernel (N <= 256; what ecgvit_attention_bwd itself runs for N <= 128):
  * an independent implementation of the same function, exported so that tests can hold the persistent kernel against it. */
 int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,

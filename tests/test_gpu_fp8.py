@@ -276,3 +276,42 @@ def test_weight_gradient_8bit_operands_vs_f32_product(afmt, shape):
         C.fill_(float('nan'))
         hip.gemm(hip.GEMM_TN, Ai.view(torch.uint8), Bi.view(torch.uint8), C, M, N, K, M, N, N, fp8_format=afmt, scale_a=one, scale_b=one, workspace=ws)
         assert torch.equal(C, want)
+
+
+@pytest.mark.parametrize('N,p', [(251, 0.1), (501, 0.0), (200, 0.1)])
+def test_attention_kernels_emit_their_8bit_copies(N, p):
+    """ecgvit_attention_fwd_q8 / _bwd_q8 = the plain kernels bit for bit (out, lse, dqkv) + the e4m3 copy of `out` / the e5m2 copy of
+    `dqkv`, equal to torch's float8 casts of those tensors over the given scales, and their amax (one and two key windows)"""
+    B, h, dh = 20, 4, 64
+    d = h * dh
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * d, generator=g).to(BF16).cuda()
+    do = torch.randn(B * N, d, generator=g).to(BF16).cuda()
+    out, out2 = (torch.zeros(B * N, d, device='cuda', dtype=BF16) for _ in range(2))
+    lse, lse2 = (torch.zeros(B * h * N, device='cuda') for _ in range(2))
+    check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, dh, 0.125, p, 7, hip.BF16, stream()), 'fwd')
+    s_out = (out.float().abs().max() / 448.0 * 1.3).reshape(1)
+    out8 = torch.full((B * N, d), 0x7F, dtype=torch.uint8, device='cuda')
+    amax = torch.zeros(1, device='cuda')
+    check(lib().ecgvit_attention_fwd_q8(ptr(qkv), ptr(out2), ptr(lse2), B, N, h, dh, 0.125, p, 7, ptr(out8), ptr(s_out), ptr(amax), stream()), 'fwd_q8')
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    assert float(amax) == float(out.float().abs().max())
+    want = (out.float() * (1.0 / s_out)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    got = out8.view(torch.float8_e4m3fn)
+    same = (got.view(torch.uint8) == want.view(torch.uint8)) | ((got.float() == 0) & (want.float() == 0))
+    assert float(same.float().mean()) > 0.9999
+    dq, dq2 = (torch.zeros(B * N, 3 * d, device='cuda', dtype=BF16) for _ in range(2))
+    check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dq), B, N, h, dh, 0.125, p, 7, hip.BF16, stream()), 'bwd')
+    s_dq = (dq.float().abs().max() / 57344.0 * 1.3).reshape(1)
+    dq8 = torch.full((B * N, 3 * d), 0x7F, dtype=torch.uint8, device='cuda')
+    amax.zero_()
+    rc = lib().ecgvit_attention_bwd_q8(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dq2), B, N, h, dh, 0.125, p, 7, ptr(dq8), ptr(s_dq), ptr(amax), stream())
+    assert rc == 0
+    assert torch.equal(dq, dq2)
+    assert float(amax) == float(dq.float().abs().max())
+    want = (dq.float() * (1.0 / s_dq)).clamp(-57344.0, 57344.0).to(torch.float8_e5m2)
+    got = dq8.view(torch.float8_e5m2)
+    same = (got.view(torch.uint8) == want.view(torch.uint8)) | ((got.float() == 0) & (want.float() == 0))
+    assert float(same.float().mean()) > 0.9999, float(same.float().mean())
+    # short sequences run the one-item kernel, which does not emit: the entry point says so instead of leaving the copy unwritten
+    assert lib().ecgvit_attention_bwd_q8(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dq2), 2, 100, h, dh, 0.125, p, 7, ptr(dq8), ptr(s_dq), ptr(amax), stream()) == 1
