@@ -46,3 +46,40 @@ def test_gemm_desc_matches_header_field_order():
         for i, d in enumerate(decl):
             names.append(re.findall(r'([A-Za-z_0-9]+)\s*$', d.strip())[0])
     assert names == [f[0] for f in E.hip.GemmDesc._fields_]
+
+
+def test_gemm_kernel_route_query_is_host_only():
+    """ecgvit_gemm_kernel answers which kernel family ecgvit_gemm would launch -- pure host logic (nothing is launched, no pointer is
+    dereferenced), so it runs without a GPU: the dispatch bench.py's probe relies on, pinned per launch type of the train step"""
+    hip = E.hip
+    l = hip.lib()
+
+    def route(layout, dtype, out_dtype, M, N, K, lda, ldb, ldc, epilogue=0, aux=False, res=False, ws=False):
+        d = hip.GemmDesc()
+        d.layout, d.dtype, d.out_dtype, d.epilogue = layout, dtype, out_dtype, epilogue
+        d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, 1, 1
+        d.A, d.B, d.C = 0x10000000, 0x20000000, 0x30000000           # never dereferenced: alignment is all that is looked at
+        d.lda, d.ldb, d.ldc = lda, ldb, ldc
+        d.bias = 0x40000000
+        d.alpha = 1.0
+        if aux:
+            d.aux, d.ldaux = 0x50000000, N
+        if res:
+            d.residual, d.ldr = 0x60000000, N
+        if ws:
+            d.workspace, d.workspace_bytes, d.colsum_out = 0x70000000, 1 << 30, 0x78000000
+        return l.ecgvit_gemm_kernel(ctypes.byref(d))
+    M, dm, f = 512 * 251, 768, 3072
+    UP = hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX | hip.EPI_DROPOUT
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M, 3 * dm, dm, dm, dm, 3 * dm) == hip.KERNEL_GEMM_NT                       # QKV forward
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M, f, dm, dm, dm, f, epilogue=UP, aux=True) == hip.KERNEL_GEMM_NT            # FFN-up forward
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M, f, dm, dm, dm, f, epilogue=hip.EPI_MUL_AUX | hip.EPI_COLSUM, aux=True, ws=True) == hip.KERNEL_GEMM_NT
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, 2000, dm, dm, dm, dm, dm) == hip.KERNEL_GEMM_BF16                             # short batch: 128^2 kernel
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M // 251 * 250, dm, 240, 240, 240, dm, epilogue=hip.EPI_BIAS) == hip.KERNEL_GEMM_BF16   # patch embed (K = 240)
+    assert route(hip.GEMM_TN, hip.BF16, hip.F32, 3 * dm, dm, M, 3 * dm, dm, dm, ws=True) == hip.KERNEL_GEMM_WGRAD                 # QKV weight gradient
+    assert route(hip.GEMM_TN, hip.BF8_E5M2, hip.F32, 3072, 1024, 256 * 501, 3072, 1024, 1024, ws=True) == hip.KERNEL_GEMM_WGRAD   # 8-bit weight gradient
+    assert route(hip.GEMM_NT, hip.FP8_E4M3, hip.BF16, 256 * 501, 4096, 1024, 1024, 1024, 4096) == hip.KERNEL_GEMM_NT              # 8-bit forward
+    assert route(hip.GEMM_NT, hip.FP8_E4M3, hip.BF16, 1000, 4096, 1024, 1024, 1024, 4096) == hip.KERNEL_NONE                      # 8-bit: large shapes only
+    assert route(hip.GEMM_NN, hip.F32, hip.F32, 100, 64, 32, 32, 64, 64) == hip.KERNEL_GEMM_F32
+    assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M, dm + 4, dm, dm, dm, dm + 4) == hip.KERNEL_NONE                              # N % 8 != 0: rejected
+    assert l.ecgvit_gemm_kernel(None) == hip.KERNEL_NONE
