@@ -12,7 +12,7 @@ bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'nt8', 'tn', 'attn'])
+    kind = rng.choice(['nt', 'nt', 'nt8', 'tn', 'tn8', 'attn', 'attn8'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -57,6 +57,43 @@ while time.time() < t_end:
             if not torch.equal(C, ref):
                 bad += 1; print('TN MISMATCH', M, N, K, int((C != ref).sum()), flush=True)
         n_tn += 1
+    elif kind == 'tn8':     # 8-bit weight gradients (e5m2 / e4m3 x e4m3, transposed 8-bit LDS reads), small integers: exact; ragged K
+        M = 256 * rng.randrange(1, 13); N = 256 * rng.randrange(1, 17)
+        K = rng.randrange(4096, 140000)
+        afmt, adt = rng.choice([(hip.FP8_E4M3, torch.float8_e4m3fn), (hip.BF8_E5M2, torch.float8_e5m2)])
+        A = torch.randint(-2, 3, (K, M), device='cuda').float().to(adt); B = torch.randint(-2, 3, (K, N), device='cuda').float().to(torch.float8_e4m3fn)
+        ref = A.float().t() @ B.float()
+        ws = torch.empty(max(16, hip.gemm_workspace_bytes(hip.GEMM_TN, bf, M, N, K)), dtype=torch.uint8, device='cuda')
+        C = torch.empty(M, N, device='cuda')
+        one = torch.ones(1, device='cuda')
+        for _ in range(3):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_TN, A.view(torch.uint8), B.view(torch.uint8), C, M, N, K, M, N, N, workspace=ws, fp8_format=afmt, scale_a=one, scale_b=one)
+            if not torch.equal(C, ref):
+                bad += 1; print('TN8 MISMATCH', M, N, K, afmt, int((C != ref).sum()), flush=True)
+        n_tn += 1
+    elif kind == 'attn8':   # the emitting attention kernels against the plain ones: same bf16 results bit for bit, 8-bit copies = casts of them
+        h = rng.choice([1, 2, 5, 12]); N = rng.randrange(129, 513); B = rng.choice([3, 40, 90]) if h < 12 else rng.choice([8, 30])
+        p = rng.choice([0.0, 0.1]); d = h * 64
+        qkv = (torch.randn(B * N, 3 * d, device='cuda') * 1.2).to(bf); do = torch.randn(B * N, d, device='cuda').to(bf)
+        out, out2 = (torch.empty(B * N, d, device='cuda', dtype=bf) for _ in range(2)); lse, lse2 = (torch.zeros(B * h * N, device='cuda') for _ in range(2))
+        check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'f')
+        sc = (out.float().abs().max() / 448.0).reshape(1).clamp_min(1e-6); am = torch.zeros(1, device='cuda')
+        o8 = torch.zeros(B * N, d, dtype=torch.uint8, device='cuda')
+        check(lib().ecgvit_attention_fwd_q8(ptr(qkv), ptr(out2), ptr(lse2), B, N, h, 64, 0.125, p, 77, ptr(o8), ptr(sc), ptr(am), stream()), 'f8')
+        w8 = (out.float() / sc).clamp(-448, 448).to(torch.float8_e4m3fn)
+        ok = torch.equal(out, out2) and torch.equal(lse, lse2) and float(((o8.view(torch.float8_e4m3fn).float() - w8.float()).abs() > 0).float().mean()) < 1e-4
+        r1, r2 = (torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=bf) for _ in range(2))
+        check(lib().ecgvit_attention_bwd(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r1), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
+        sc2 = (r1.float().abs().max() / 57344.0).reshape(1).clamp_min(1e-9); am.zero_()
+        g8 = torch.zeros(B * N, 3 * d, dtype=torch.uint8, device='cuda')
+        check(lib().ecgvit_attention_bwd_q8(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r2), B, N, h, 64, 0.125, p, 77, ptr(g8), ptr(sc2), ptr(am), stream()), 'b8')
+        wg = (r1.float() / sc2).clamp(-57344, 57344).to(torch.float8_e5m2)
+        ok = ok and torch.equal(r1, r2) and float(am) == float(r1.float().abs().max()) and \
+            float(((g8.view(torch.float8_e5m2).float() - wg.float()).abs() > 0).float().mean()) < 1e-4
+        if not ok:
+            bad += 1; print('ATTN8 MISMATCH', B, h, N, p, flush=True)
+        n_at += 1
     else:
         h = rng.choice([1, 2, 3, 5, 12]); N = rng.randrange(129, 513); B = rng.choice([3, 40, 90, 300]) if h < 12 else rng.choice([8, 30, 64])
         p = rng.choice([0.0, 0.1, 0.3]); d = h * 64
