@@ -306,6 +306,7 @@ int64_t ecgvit_gemm_wgrad_workspace(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s);
 bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d);
 int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);
+int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);   // gemm_nt.hip: the four-wave body
 
 extern "C" int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d) {
     if ((d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) && d->layout == ECGVIT_GEMM_TN) return ecgvit_gemm_wgrad_workspace(d);
@@ -431,6 +432,7 @@ extern "C" int ecgvit_gemm_kernel(const ecgvit_gemm_desc *d) {
 extern "C" int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g, int diag) {
     if (!d) return ECGVIT_EINVAL;
     if (kernel == 2) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt_launch(d, as_stream(stream), raster_g, diag) : ECGVIT_EINVAL;
+    if (kernel == 3) return ecgvit_gemm_nt_applicable(d) ? ecgvit_gemm_nt4w_launch(d, as_stream(stream), raster_g, diag) : ECGVIT_EINVAL;
     return ecgvit_gemm(d, stream);
 }
 #endif

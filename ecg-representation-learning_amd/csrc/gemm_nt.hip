@@ -131,12 +131,17 @@ __device__ __forceinline__ void nt_epi8_tail(const u32x4 &out, bool ok, bool okm
     }
 }
 
-template <typename TO, int FL>
+template <typename TO, int FL, int CAUX = 0>
 __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint32_t m, uint32_t ncol, bool ok, uint32_t mm, uint32_t ncm, bool okm,
                                         const NtBufs &bf, const EpiParams &e, const u32x4 &res, const u32x4 &auxin, float *cs8, float &qmax) {
-    if (e.alpha != 1.f) {   // wave-uniform
+    // light bodies: alpha was applied to the accumulators by nt_epilogue, behind ONE branch (unrolled, the compiler turns this one into
+    // a select per element).  The rolled heavy bodies keep it here, where it is a real branch
+    constexpr bool kLightBody = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
+    if constexpr (!kLightBody) {
+        if (e.alpha != 1.f) {   // wave-uniform
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
+            for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
+        }
     }
     if (NT_HAS(ECGVIT_EPI_BIAS)) {
 #pragma unroll
@@ -164,7 +169,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
             for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
         }
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX & 0xFF);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
         return;
     }
@@ -216,7 +221,10 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, 0);
+        if constexpr ((CAUX & 0x100) != 0)   // EXPERIMENT: straight from the accumulator layout (16 rows x 4 runs of 16 B per instruction), no lane permute
+            __builtin_amdgcn_raw_buffer_store_b128(out, bf.c, ok ? m * (uint32_t)bf.ldc2 + ncol * 2 : NT_OOB, 0, CAUX & 0xFF);
+        else
+            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, CAUX & 0xFF);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax, e.flags);
     } else {   // f32 outputs: 32 B per lane stay in the accumulator layout (no train-step launch takes this branch)
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
@@ -239,7 +247,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 // own up-front loads (bias, residual / aux rows) and BEFORE its first store: vmcnt retires in issue order, so pieces issued ahead of
 // those loads would have to land (an HBM round trip, with the matrix pipe idle) before the first row of the epilogue could start,
 // and pieces issued behind the stores would hold the next main loop until the stores are acknowledged.
-template <typename TO, int FL, typename IssueNext>
+template <typename TO, int FL, int CAUX = 0, typename IssueNext>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gemm_desc &d, const EpiParams &e, const NtBufs &bf, int m0, int n0,
                                             int wave, int lane, IssueNext &&issue_next) {
     const int wm = wave >> 2, wn = wave & 3;
@@ -262,6 +270,17 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll
     for (int k = 0; k < 16; ++k) cs[k] = 0.f;
     float qmax = 0.f;
+    if (FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD)) && e.alpha != 1.f) {
+        // light bodies: a REAL wave-uniform branch (the empty asm keeps the compiler from if-converting it): as a select per element it cost every
+        // launch with a light body 1.5 VALU instructions per element, alpha == 1 included -- a third of the plain epilogue
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] *= e.alpha;
+    }
     const uint32_t mrow = (uint32_t)(m0 + wm * 128 + c);
     // memory layout of a 16-row x 32-column half block: lane t moves row t>>2, run t&3 (accumulator layout: row s&15, run s>>4)
     const uint32_t mrowm = (uint32_t)(m0 + wm * 128 + (lane >> 2));
@@ -295,8 +314,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc(X[i][0], want_aux), cs, qmax);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(R[i][1], want_res), to_acc(X[i][1], want_aux),
+            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc(X[i][0], want_aux), cs, qmax);
+            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(R[i][1], want_res), to_acc(X[i][1], want_aux),
                             cs + 8, qmax);
         }
     } else {
@@ -325,8 +344,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #undef NT_PICK
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
-            nt_epi8<TO, FL>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc(a0, want_aux), cs, qmax);
-            nt_epi8<TO, FL>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc(a1, want_aux), cs + 8, qmax);
+            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc(a0, want_aux), cs, qmax);
+            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc(a1, want_aux), cs + 8, qmax);
         }
     }
     if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // one atomic max per wave and tile (non-negative floats order as integers)
@@ -364,7 +383,7 @@ __device__ unsigned long long g_nt_stamps[256 * 8];
 #define NT_STAMP_T() 0ull
 #endif
 
-template <typename TO, int FL, bool STAMP = false, int OPS = 0>
+template <typename TO, int FL, bool STAMP = false, int OPS = 0, int CAUX = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems, int ablate) {
     __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
     const int M = d.M, N = d.N;
@@ -651,7 +670,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             }
         };
         [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
-        nt_epilogue<TO, FL>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next);
+        nt_epilogue<TO, FL, CAUX>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next);
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
         if (!has_next) break;
         it = next_it;
@@ -676,6 +695,252 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #undef R_ADV_A
 #undef R_ADV_B
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// gemm_nt_kernel_4w: the same tile, LDS images, ring, tile walk and epilogue with FOUR waves -- one per SIMD, each owning a 128 x 128
+// block of the tile in 256 accumulator registers (the kernel's 512 registers per lane = one wave per SIMD).  Every A fragment feeds
+// eight MFMAs instead of four (128 KB of fragment reads per K-tile and CU instead of 192), and ONE instruction stream per SIMD carries
+// the 64 MFMAs of a 32-deep k-step with the next k-step's 16 fragment reads and eight DMA pieces placed between them, in a fixed
+// order (the way the vendor library's own 256x256x64 kernel is written; profiles/r03_gemm_4w.txt).  Its main loop costs ~2,500 cycles
+// per K-tile where the eight-wave kernel's costs ~2,870 (2,048 = MFMA alone), but its epilogue runs on ONE wave per SIMD -- half the
+// VALU issue rate of two -- so it serves the launches whose time is main loop: plain products with K >= 1536 (the QKV and FFN-up
+// input gradients).  Results are bit-identical to gemm_nt_kernel's (same MFMA, same K order, same epilogue code).
+template <int... X, typename F>
+__device__ __forceinline__ void q4_static_for_impl(std::integer_sequence<int, X...>, F &&f) { (f(std::integral_constant<int, X>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void q4_static_for(F &&f) { q4_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+// where in a k-step's 64 MFMAs the 16 fragment reads and 8 DMA pieces go (index of the read / piece issued behind MFMA x, or -1): one
+// read per four MFMAs, one piece per eight.  (Measured against two reads + one piece per eight MFMAs: equal; against the pieces
+// front-loaded one per four MFMAs: 0-3 % slower.)
+__device__ constexpr int q4_read_at(int x) { return (x & 3) == 1 ? x >> 2 : -1; }
+__device__ constexpr int q4_dma_at(int x) { return (x & 7) == 3 ? x >> 3 : -1; }
+template <typename TO, int FL, int CAUX = 0, bool STAMP = false>
+__global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, EpiParams e, int tiles_m, int tiles_n, int ngroup, int nitems, int ablate) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    e.alpha = 1.f;   // (the launcher takes alpha == 1 only: the epilogue's scaling branch folds away)
+    const int M = d.M, N = d.N;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = d.K / BK;
+    const int lda2 = (int)d.lda * 2, ldb2 = (int)d.ldb * 2;
+    const int ntile = tiles_m * tiles_n;
+    int it = blockIdx.x;
+    if (it >= nitems) return;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)M * lda2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
+    NtBufs bf;
+    bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * 2;
+    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (STAMP && (ablate & 1)) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1: stores dropped
+    bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
+    bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
+    bf.ldq = 0; bf.q8 = bf.aux; bf.q8_bf8 = false; bf.q8_inv = 0.f;
+    bf.t_out = ((lane >> 2) + 16 * (lane & 3)) << 2;
+    bf.t_in = (4 * (lane & 15) + (lane >> 4)) << 2;
+    // this wave's four DMA pieces of a half-tile: rows 32*wave + 8*i + (lane >> 3)
+    // (recomputed behind every epilogue from an opaque copy of the lane id: kept live across the epilogue they are spilled, and hipcc then
+    // guards every DMA piece of the main loop with a vmcnt wait for the reload)
+    int voA[4], voB[4];
+    auto calc_vo = [&]() __attribute__((always_inline)) {
+        int ln;   // the lane id, from the hardware each time (a live copy across the main loop is what gets spilled)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 32 * wave + 8 * i + (ln >> 3), p = ln & 7;
+            voA[i] = r * lda2 + ((p ^ ((r >> 1) & 7)) << 4);
+            const int fw = (((r >> 3) & 3) << 1) | ((r >> 1) & 1);
+            voB[i] = r * ldb2 + ((p ^ fw) << 4);
+        }
+    };
+    calc_vo();
+    const int fr = lane & 15, fq = lane >> 4;
+    const int loff = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);
+    const int rl = 8 * (fr >> 2) + (fr & 3);
+    const int boff = rl * 128 + ((fq ^ (((fr >> 2) << 1) | ((fr >> 1) & 1))) << 4);   // n-tile j of column group g: + 8192 g + 512 (j&1) + 4096 (j>>1)
+
+#define Q_DMA_A(h, ring, soff)                                                                                \
+    do {                                                                                                      \
+        char *dst_ = smem + (3 * (h) + (ring)) * HALF_BYTES + wave * 4096;                                    \
+        const int so_ = (soff) + (h) * 128 * lda2;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(dst_ + 1024 * i_), 16, voA[i_], so_, 0, 0); \
+    } while (0)
+#define Q_DMA_B(h, ring, soff)                                                                                \
+    do {                                                                                                      \
+        char *dst_ = smem + (6 + 2 * (h) + (ring)) * HALF_BYTES + wave * 4096;                                \
+        const int so_ = (soff) + (h) * 128 * ldb2;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                      \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(dst_ + 1024 * i_), 16, voB[i_], so_, 0, 0); \
+    } while (0)
+
+    int cm0, cn0, nm0, nn0;
+    decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
+    nm0 = cm0; nn0 = cn0;
+    // producer cursors; past the end of this workgroup's share they stay where they are (harmless re-reads into free slots): the
+    // pieces are issued unconditionally so that a k-step stays ONE scheduling region
+    int a_it = it, a_kt = 0, a_base = cm0 * lda2;
+    int b_it = it, b_kt = 0, b_base = cn0 * ldb2;
+#define Q_ADV_A()                                                                                             \
+    do {                                                                                                      \
+        if (++a_kt == nk) {                                                                                   \
+            a_kt = 0;                                                                                         \
+            if (a_it + (int)gridDim.x < nitems) { a_it += (int)gridDim.x; decode_tile(a_it, ntile, tiles_m, tiles_n, ngroup, nm0, nn0); a_base = nm0 * lda2; } \
+        }                                                                                                     \
+    } while (0)
+#define Q_ADV_B()                                                                                             \
+    do {                                                                                                      \
+        if (++b_kt == nk) {                                                                                   \
+            b_kt = 0;                                                                                         \
+            if (b_it + (int)gridDim.x < nitems) { b_it += (int)gridDim.x; b_base = nn0 * ldb2; }              \
+        }                                                                                                     \
+    } while (0)
+    // fragments of one 32-deep k-step: 8 n-tiles of B (reads 0-7), 8 m-tiles of A (reads 8-15)
+#define Q_READ1(AF, BFR, SA, SB, S, R)                                                                        \
+    do {                                                                                                      \
+        if ((R) < 8) BFR[(R) & 7] = *reinterpret_cast<const bf16x8 *>(smem + (((SB) + 8192 * (((R) & 7) >> 2) + 512 * ((R) & 1) + 4096 * (((R) >> 1) & 1)) ^ ((S) * 64))); \
+        else AF[(R) & 7] = *reinterpret_cast<const bf16x8 *>(smem + (((SA) + ((R) & 7) * 2048) ^ ((S) * 64))); \
+    } while (0)
+#define Q_READ(AF, BFR, GA, GB, S)                                                                            \
+    do {                                                                                                      \
+        const int sa_ = (3 * wm + (GA)) * HALF_BYTES + loff, sb_ = (6 + 2 * wn + (GB)) * HALF_BYTES + boff;   \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) Q_READ1(AF, BFR, sa_, sb_, S, r_);                  \
+    } while (0)
+#define Q_MMA1(AF, BFR, X)                                                                                    \
+    acc[((X) & 7) >> 2][(X) >> 3][(X) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BFR[(X) & 7], AF[(X) >> 3], acc[((X) & 7) >> 2][(X) >> 3][(X) & 3], 0, 0, 0)
+#define Q_FENCE() __builtin_amdgcn_sched_barrier(0)
+    // ONE k-step in issue order: 64 MFMAs from (AF, BFR); between them the 16 fragment reads of the next k-step into (AN, BN) and, with
+    // DMA, eight pieces (RS / VO / pitch LD, half-tiles 0 and 1 into LDS at D0 / D1, source offset SO).  Fenced so that the order stays.
+#define Q_KSTEP(AF, BFR, AN, BN, GA, GB, S, RD, DMA, RS, VO, LD, D0, D1, SO)                                      \
+    do {                                                                                                      \
+        const int sa_ = (3 * wm + (GA)) * HALF_BYTES + loff, sb_ = (6 + 2 * wn + (GB)) * HALF_BYTES + boff;   \
+        q4_static_for<64>([&](auto xc_) __attribute__((always_inline)) {                                      \
+            constexpr int x_ = decltype(xc_)::value, r_ = q4_read_at(x_), p_ = q4_dma_at(x_);                 \
+            Q_MMA1(AF, BFR, x_);                                                                              \
+            if constexpr ((RD) && r_ >= 0) { Q_FENCE(); Q_READ1(AN, BN, sa_, sb_, S, r_); Q_FENCE(); }        \
+            if constexpr ((DMA) && p_ >= 0) {                                                                 \
+                Q_FENCE();                                                                                    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lptr_t)((p_ < 4 ? (D0) : (D1)) + 1024 * (p_ & 3)), 16, VO[p_ & 3], \
+                                                         (SO) + (p_ < 4 ? 0 : 128 * (LD)), 0, 0);              \
+                Q_FENCE();                                                                                    \
+            }                                                                                                 \
+        });                                                                                                   \
+        Q_FENCE();                                                                                            \
+    } while (0)
+
+    bf16x8 a0[8], b0[8];
+    // prologue: A(0), B(0), A(1); behind the barrier the first k-step's fragments, B(1) and A(2)
+    Q_DMA_A(0, 0, a_base); Q_DMA_A(1, 0, a_base); Q_ADV_A();
+    Q_DMA_B(0, 0, b_base); Q_DMA_B(1, 0, b_base); Q_ADV_B();
+    Q_DMA_A(0, 1, a_base + a_kt * (BK * 2)); Q_DMA_A(1, 1, a_base + a_kt * (BK * 2)); Q_ADV_A();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Q_READ(a0, b0, 0, 0, 0);
+    Q_DMA_B(0, 1, b_base + b_kt * (BK * 2)); Q_DMA_B(1, 1, b_base + b_kt * (BK * 2)); Q_ADV_B();
+    Q_DMA_A(0, 2, a_base + a_kt * (BK * 2)); Q_DMA_A(1, 2, a_base + a_kt * (BK * 2)); Q_ADV_A();
+    int ga = 0, gb = 0;
+    bool first = true;
+    constexpr int NST = 2 * (sizeof(TO) == 2 ? 16 : 32);   // the epilogue's output stores
+    [[maybe_unused]] unsigned long long st_t0 = 0, st_r0 = 0, st_main = 0, st_epi = 0, st_ntile = 0;
+#ifdef ECGVIT_TOOLS
+    if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    for (;;) {
+        [[maybe_unused]] const unsigned long long st_a = NT_STAMP_T();
+        f32x4 acc[2][8][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[g][i][j][r] = 0.f;
+        // one K-tile; its first and last instance of a tile are separate straight-line copies (no control flow merges 256 accumulators)
+        auto ktile = [&](auto first_c, auto last_c) __attribute__((always_inline)) {
+            constexpr bool KFIRST = decltype(first_c)::value, KLAST = decltype(last_c)::value;
+            bf16x8 a1[8], b1[8];
+            const int ga1 = ga == 2 ? 0 : ga + 1, ga2 = ga == 0 ? 2 : ga - 1, gb1 = gb ^ 1;
+            // ---- k-step 0 of K-tile kt (fragments already in a0 / b0); reads of k-step 1; A(kt+2) goes out (kt = 0: already in flight)
+            Q_FENCE();
+            if constexpr (!KFIRST) {
+                Q_KSTEP(a0, b0, a1, b1, ga, gb, 1, true, true, rsA, voA, lda2, smem + ga2 * HALF_BYTES + wave * 4096, smem + (3 + ga2) * HALF_BYTES + wave * 4096,
+                        a_base + a_kt * (BK * 2));
+                Q_ADV_A();
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                Q_KSTEP(a0, b0, a1, b1, ga, gb, 1, true, false, rsA, voA, lda2, smem, smem, 0);
+                if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NST) : "memory");
+            }
+            Q_FENCE();
+            __builtin_amdgcn_s_barrier();
+            Q_FENCE();
+            // ---- k-step 1; K-tile kt+1 is visible and nobody reads K-tile kt from LDS any more: reads of (kt+1, k-step 0), B(kt+2) goes out
+            // (the last k-step of a tile reads nothing: the next tile's first fragments are fetched behind the epilogue, which needs the registers)
+            Q_KSTEP(a1, b1, a0, b0, ga1, gb1, 0, !KLAST, true, rsB, voB, ldb2, smem + (6 + gb) * HALF_BYTES + wave * 4096, smem + (8 + gb) * HALF_BYTES + wave * 4096,
+                    b_base + b_kt * (BK * 2));
+            Q_ADV_B();
+            ga = ga1; gb = gb1;
+        };
+        ktile(std::true_type{}, std::false_type{});
+#pragma unroll 1
+        for (int kt = 1; kt < nk - 1; ++kt) ktile(std::false_type{}, std::false_type{});
+        ktile(std::false_type{}, std::true_type{});
+        first = false;
+        const int next_it = it + (int)gridDim.x;
+        const bool has_next = next_it < nitems;
+        // the next tile's A(2) ahead of the stores (vmcnt retires in issue order)
+        { const int gaf = ga == 0 ? 2 : ga - 1; Q_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); Q_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); Q_ADV_A(); }
+        auto none = [&]() __attribute__((always_inline)) {};
+        [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
+        if (STAMP && (ablate & 2)) {   // ablate 2: no epilogue at all (the accumulators are consumed by one dummy store)
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += acc[g][i][j][0];
+            if (sum == 12345.678f) reinterpret_cast<float *>(d.C)[lane] = sum;
+        } else {
+        // (the epilogue's lane-derived offsets from a fresh lane id, per tile: hoisted out of the tile loop they are
+        // spilled, and the reload's `s_waitcnt vmcnt(0)` would wait for the pieces just issued)
+        int eln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
+        bf.t_out = ((eln >> 2) + 16 * (eln & 3)) << 2;
+        nt_epilogue<TO, FL, CAUX>(acc[0], d, e, bf, cm0, cn0, 4 * wm + 2 * wn, eln, none);
+        nt_epilogue<TO, FL, CAUX>(acc[1], d, e, bf, cm0, cn0, 4 * wm + 2 * wn + 1, eln, none);
+        }
+        if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
+        if (!has_next) break;
+        it = next_it;
+        decode_tile(it, ntile, tiles_m, tiles_n, ngroup, cm0, cn0);
+        calc_vo();
+        Q_READ(a0, b0, ga, gb, 0);
+    }
+    // nothing of this wave's may still be on its way into LDS when the workgroup's allocation is released (the cursors keep issuing
+    // pieces past the end of the share)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef ECGVIT_TOOLS
+    if constexpr (STAMP) {
+        if (threadIdx.x == 0) {
+            unsigned long long *o = g_nt_stamps + blockIdx.x * 8;
+            o[0] = st_t0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+            o[4] = st_main; o[5] = st_epi; o[6] = st_ntile; o[7] = (unsigned long long)nk;
+        }
+    }
+#endif
+#undef Q_DMA_A
+#undef Q_DMA_B
+#undef Q_ADV_A
+#undef Q_ADV_B
+#undef Q_READ
+#undef Q_READ1
+#undef Q_MMA1
+#undef Q_FENCE
+#undef Q_KSTEP
+}
+
 
 }  // namespace
 
@@ -704,6 +969,7 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
 
 void ecgvit_colsum_reduce_launch(const float *partial, int nparts, int N, float *out, hipStream_t s);   // gemm_wgrad.hip
 
+int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag);
 // argument validation is done by the caller (ecgvit_gemm_bf16_launch); raster_g <= 0 selects the built-in choice
 int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {
 #ifdef ECGVIT_TOOLS
@@ -762,8 +1028,27 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             default: NT_LAUNCH8(-1, 4); break;
         }
     } else if (d->out_dtype == ECGVIT_BF16) {
+        if (fl == 0) {
+            // plain products.  K >= 1536 (the QKV and FFN-up input gradients): the four-wave body -- persistent launches only, alpha 1.
+            // Outputs that do not fit the 256 MB Infinity Cache (QKV forward: 592 MB) are stored non-temporally: written through L2 they
+            // evict the operand panels the tile's neighbours are about to re-read (main loop 3,020 -> 2,620 cycles per K-tile, launch
+            // -6...-10 %); smaller outputs (197 MB) are absorbed by the cache and nt costs them 2-3 % (profiles/r03_gemm_4w.txt)
+            const bool big_out = (int64_t)d->M * d->N * 2 > (256ll << 20);
+#ifdef ECGVIT_TOOLS
+            // A/B: ECGVIT_NT_NO4W (whole step) or diag bits 128 / 256 / 512 (one launch): 1 = eight-wave body everywhere, 2 = no nt stores, 4 = nt stores everywhere
+            static const int env_no4w = [] { const char *e_ = getenv("ECGVIT_NT_NO4W"); return e_ ? atoi(e_) : 0; }();
+            const int no4w = env_no4w | ((diag >> 7) & 7);
+            const bool use4w = !(no4w & 1), use_nt = (big_out && !(no4w & 2)) || (no4w & 4);
+#else
+            const bool use4w = true, use_nt = big_out;
+#endif
+            if (use4w && d->K >= 1536 && tpw == 0 && e.alpha == 1.f && !d->scale_a && !d->scale_b) return ecgvit_gemm_nt4w_launch(d, s, raster_g, use_nt ? 2 : 0);
+            if (use_nt) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, false, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
+            else NT_LAUNCH(bf16_t, 0);
+            ECGVIT_CHECK_LAUNCH();
+            return ECGVIT_OK;
+        }
         switch (fl) {
-            case 0: NT_LAUNCH(bf16_t, 0); break;
             case ECGVIT_EPI_BIAS: NT_LAUNCH(bf16_t, ECGVIT_EPI_BIAS); break;   // the masked objective's pixel head
             case F_LIN: NT_LAUNCH(bf16_t, F_LIN); break;
             case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH(bf16_t, F_LIN | ECGVIT_EPI_DROPOUT); break;
@@ -783,6 +1068,28 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
         ecgvit_colsum_reduce_launch((const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out, s);
         ECGVIT_CHECK_LAUNCH();
     }
+    return ECGVIT_OK;
+}
+
+// the four-wave body (plain bf16 products, alpha 1, persistent grid); diag: 2 = non-temporal output stores; tools build: 1 = stamped
+// instantiation with ablate bits (diag >> 2: 1 stores dropped, 2 no epilogue)
+int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {
+    const EpiParams e = make_epi(d);
+    if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || d->epilogue != 0 || d->K < 192 || e.alpha != 1.f || d->scale_a || d->scale_b) return ECGVIT_EINVAL;
+    const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
+    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);
+    const dim3 grid((unsigned)std::min(ntile, 256)), block(256);
+#ifdef ECGVIT_TOOLS
+    if (diag & 1) {
+        if (diag & 2) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 2, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, (diag >> 2) & 3);
+        else hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 0, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, (diag >> 2) & 3);
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
+#endif
+    if (diag & 2) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
+    else hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 0>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
+    ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
 

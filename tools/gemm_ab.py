@@ -3,7 +3,8 @@
 epilogues the train step uses, all variants interleaved in ONE process on ONE device (guide rule 24).
 
 Needs the tools build (`make -C ecg-representation-learning_amd/csrc tools`): `ecgvit_tools_gemm(desc, stream, kernel, raster_g)`
-kernel 1 = retired LDS-patch kernel (gemm_bf16_q_kernel), 2 = gemm_nt_kernel; `lib` = torch.matmul (hipBLASLt), plain product only.
+kernel 1 = retired LDS-patch kernel (gemm_bf16_q_kernel), 2 = gemm_nt_kernel's dispatch (diag 128: eight-wave body only, 256 / 512: default-policy /
+non-temporal output stores), 3 = gemm_nt_kernel_4w (diag 2: non-temporal stores); `lib` = torch.matmul (hipBLASLt), plain product only.
 usage: python tools/gemm_ab.py [--rounds 5] [--iters 10] [--groups 0,1,3] [--check]
 """
 import argparse
@@ -35,6 +36,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--plain', action='store_true', help='also time every epilogue case with epilogue 0')
     ap.add_argument('--json', default='')
+    ap.add_argument('--nt4', action='store_true', help='also time the four-wave body (kernel 3) on every plain product')
     args = ap.parse_args()
     lib = hip.lib()
     tg = lib.ecgvit_tools_gemm
@@ -73,7 +75,13 @@ def main():
         if not args.no_old:
             variants.append(('old', 1, 0, 0))
         for g in groups:
-            variants.append((f'new g={g}', 2, g, 0))
+            variants.append((f'8w g={g}', 2, g, 128 | 256))          # eight-wave body, default-policy stores
+            if epi == 0:
+                variants.append((f'8w g={g} nt', 2, g, 128 | 512))   # eight-wave body, non-temporal stores
+            variants.append((f'shipped g={g}', 2, g, 0))             # what the library's dispatch picks
+        if args.nt4 and epi == 0:
+            variants.append(('4w', 3, 0, 0))
+            variants.append(('4w nt', 3, 0, 2))
         C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
         A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
         descs = {v[0]: make(C[v[0]], A[v[0]]) for v in variants}
@@ -109,14 +117,14 @@ def main():
             print(f'{name:15s} K={K:4d} N={N:4d} epi={epi:3d}  {n:16s}: median {med:7.1f} us  min {mn:7.1f} us  {fl / med / 1e6:7.1f} TFLOP/s '
                   f'({100 * fl / med / 1e6 / 2500:4.1f} %)', flush=True)
             results.append(dict(case=name, K=K, N=N, epilogue=epi, variant=n, median_us=med, min_us=mn, tflops=fl / med / 1e6))
-        if args.check and len(variants) >= 2 and variants[0][0] == 'old':
-            ref = C['old'].float()
+        if args.check and len(variants) >= 2:
+            ref = C[variants[0][0]].float()
             for v in variants[1:]:
                 dlt = (C[v[0]].float() - ref).abs()
-                same = (C[v[0]] == C['old']).float().mean().item()
+                same = (C[v[0]] == C[variants[0][0]]).float().mean().item()
                 msg = f'   check {v[0]}: max|new-old| {dlt.max().item():.3e}  identical {100 * same:.4f} %'
                 if aux is not None and epi & EPI_GELU:
-                    msg += f'  aux identical {100 * (A[v[0]] == A["old"]).float().mean().item():.4f} %'
+                    msg += f'  aux identical {100 * (A[v[0]] == A[variants[0][0]]).float().mean().item():.4f} %'
                 print(msg, flush=True)
         if args.check:
             # f32 reference on a row sample (plain product + bias only cases get the full check elsewhere: tests/test_gpu_ops.py)
