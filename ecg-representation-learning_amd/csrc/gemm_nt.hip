@@ -839,7 +839,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
     Q_DMA_A(0, 2, a_base + a_kt * (BK * 2)); Q_DMA_A(1, 2, a_base + a_kt * (BK * 2)); Q_ADV_A();
     int ga = 0, gb = 0;
     bool first = true;
-    constexpr int NST = 2 * (sizeof(TO) == 2 ? 16 : 32);   // the epilogue's output stores
+    // vector-memory instructions the epilogue issues BEHIND the pieces it sends ahead: the output stores of both column halves and the
+    // second half's row loads
+    constexpr int NST = 2 * (sizeof(TO) == 2 ? 16 : 32) + ((FL & ECGVIT_EPI_RESIDUAL) ? 16 : 0) + ((FL & ECGVIT_EPI_MUL_AUX) ? 16 : 0);
+    static_assert(FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_ACCUM | ECGVIT_EPI_QUANT_OUT)) && 8 + NST <= 63, "light bodies only");
     [[maybe_unused]] unsigned long long st_t0 = 0, st_r0 = 0, st_main = 0, st_epi = 0, st_ntile = 0;
 #ifdef ECGVIT_TOOLS
     if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -889,8 +892,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
         first = false;
         const int next_it = it + (int)gridDim.x;
         const bool has_next = next_it < nitems;
-        // the next tile's A(2) ahead of the stores (vmcnt retires in issue order)
-        { const int gaf = ga == 0 ? 2 : ga - 1; Q_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); Q_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); Q_ADV_A(); }
+        // the next tile's A(2) goes out from inside the epilogue of the first column half: behind that half's own row loads (residual),
+        // ahead of every store (vmcnt retires in issue order; see nt_epilogue)
+        auto issue_next = [&]() __attribute__((always_inline)) {
+            const int gaf = ga == 0 ? 2 : ga - 1;
+            Q_DMA_A(0, gaf, a_base + a_kt * (BK * 2)); Q_DMA_A(1, gaf, a_base + a_kt * (BK * 2)); Q_ADV_A();
+        };
         auto none = [&]() __attribute__((always_inline)) {};
         [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
         if (STAMP && (ablate & 2)) {   // ablate 2: no epilogue at all (the accumulators are consumed by one dummy store)
@@ -908,7 +915,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
         int eln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
         bf.t_out = ((eln >> 2) + 16 * (eln & 3)) << 2;
-        nt_epilogue<TO, FL, CAUX>(acc[0], d, e, bf, cm0, cn0, 4 * wm + 2 * wn, eln, none);
+        nt_epilogue<TO, FL, CAUX>(acc[0], d, e, bf, cm0, cn0, 4 * wm + 2 * wn, eln, issue_next);
         nt_epilogue<TO, FL, CAUX>(acc[1], d, e, bf, cm0, cn0, 4 * wm + 2 * wn + 1, eln, none);
         }
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
@@ -1048,6 +1055,18 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             ECGVIT_CHECK_LAUNCH();
             return ECGVIT_OK;
         }
+        // the two residual launches (bias + residual [+ dropout]: attn-out and FFN-down forward) with K >= 768: the four-wave body as well --
+        // its shorter main loop outweighs the one-wave epilogue (launch -2 % at K = 768, -3 % at K = 3072; step +0.2...0.3 %)
+        {
+#ifdef ECGVIT_TOOLS
+            static const int env_no4w = [] { const char *e_ = getenv("ECGVIT_NT_NO4W"); return e_ ? atoi(e_) : 0; }();
+            const bool use4w = !((env_no4w | (diag >> 7)) & 1);
+#else
+            const bool use4w = true;
+#endif
+            if (use4w && (fl & ~ECGVIT_EPI_DROPOUT) == F_LIN && d->K >= 768 && tpw == 0 && e.alpha == 1.f && !d->scale_a && !d->scale_b)
+                return ecgvit_gemm_nt4w_launch(d, s, raster_g, 0);
+        }
         switch (fl) {
             case ECGVIT_EPI_BIAS: NT_LAUNCH(bf16_t, ECGVIT_EPI_BIAS); break;   // the masked objective's pixel head
             case F_LIN: NT_LAUNCH(bf16_t, F_LIN); break;
@@ -1071,24 +1090,31 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     return ECGVIT_OK;
 }
 
-// the four-wave body (plain bf16 products, alpha 1, persistent grid); diag: 2 = non-temporal output stores; tools build: 1 = stamped
+// the four-wave body (bf16 products, plain or bias + residual [+ dropout], alpha 1, persistent grid); diag: 2 = non-temporal output stores (plain); tools build: 1 = stamped
 // instantiation with ablate bits (diag >> 2: 1 stores dropped, 2 no epilogue)
 int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {
     const EpiParams e = make_epi(d);
-    if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || d->epilogue != 0 || d->K < 192 || e.alpha != 1.f || d->scale_a || d->scale_b) return ECGVIT_EINVAL;
+    constexpr int F_LIN = ECGVIT_EPI_BIAS | ECGVIT_EPI_RESIDUAL;
+    const int fl = d->epilogue;
+    if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || d->K < 192 || e.alpha != 1.f || d->scale_a || d->scale_b) return ECGVIT_EINVAL;
+    if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT)) return ECGVIT_EINVAL;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);
     const dim3 grid((unsigned)std::min(ntile, 256)), block(256);
+#define NT4W_GO(FL, CAUX, ST, AB) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, FL, CAUX, ST>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, AB)
 #ifdef ECGVIT_TOOLS
-    if (diag & 1) {
-        if (diag & 2) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 2, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, (diag >> 2) & 3);
-        else hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 0, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, (diag >> 2) & 3);
+    if ((diag & 1) && fl == 0) {
+        if (diag & 2) NT4W_GO(0, 2, true, (diag >> 2) & 3);
+        else NT4W_GO(0, 0, true, (diag >> 2) & 3);
         ECGVIT_CHECK_LAUNCH();
         return ECGVIT_OK;
     }
 #endif
-    if (diag & 2) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
-    else hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, 0, 0>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
+    if (fl == F_LIN) NT4W_GO(F_LIN, 0, false, 0);
+    else if (fl == (F_LIN | ECGVIT_EPI_DROPOUT)) NT4W_GO(F_LIN | ECGVIT_EPI_DROPOUT, 0, false, 0);
+    else if (diag & 2) NT4W_GO(0, 2, false, 0);
+    else NT4W_GO(0, 0, false, 0);
+#undef NT4W_GO
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

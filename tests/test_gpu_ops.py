@@ -621,6 +621,37 @@ def test_gemm_bf16_persistent_forward_is_race_free_and_exact():
         assert torch.equal(Cb, ref.to(BF16))
 
 
+def test_gemm_bf16_four_wave_body_is_race_free_exact_and_equal_to_the_eight_wave_body():
+    """plain bf16 products with K >= 1536 run on gemm_nt_kernel_4w (one wave per SIMD, 128 x 128 per wave, fixed-order k-steps); outputs of
+    more than 256 MB are stored non-temporally (either body).  Small-integer operands make the result exact: it must EQUAL the integer
+    reference on every repeated launch (ragged M and N, one to many tiles per workgroup, K-tile counts 24 to 48), and the chunked launch
+    of the same product -- which stays on the eight-wave body -- must give the same bits."""
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K) in ((66001, 776, 1536), (9000, 768, 3072), (2259, 2304, 2304), (60011, 2304, 1536), (60011, 2304, 768)):
+        A = torch.randint(-3, 4, (M, K), generator=g).float()
+        B = torch.randint(-3, 4, (N, K), generator=g).float()
+        Ad, Bd = A.to(BF16).cuda(), B.to(BF16).cuda()
+        ref = (Ad.float() @ Bd.float().t()).to(BF16)            # exact before the bf16 rounding: |sum| <= 9 * 3072 < 2^24
+        assert hip.gemm_kernel(hip.GEMM_NT, Ad, Bd, ref, M, N, K, K, K, N) == hip.KERNEL_GEMM_NT
+        C = torch.empty(M, N, device='cuda', dtype=BF16)
+        for rep in range(6):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N)
+            assert torch.equal(C, ref), (M, N, K, rep, int((C != ref).sum()))
+        C.fill_(float('nan'))
+        hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N, tiles_per_workgroup=2)
+        assert torch.equal(C, ref), (M, N, K, 'chunked')
+    # random operands: the two bodies accumulate in the same order -- identical bits, not just close
+    M, N, K = 20000, 1000, 2304
+    Ad = torch.randn(M, K, generator=g).to(BF16).cuda()
+    Bd = (torch.randn(N, K, generator=g) * 0.05).to(BF16).cuda()
+    C4, C8 = torch.empty(M, N, device='cuda', dtype=BF16), torch.empty(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C4, M, N, K, K, K, N)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C8, M, N, K, K, K, N, tiles_per_workgroup=3)
+    assert torch.equal(C4, C8)
+    assert rel_err(C4, Ad.double() @ Bd.double().t()) < 4e-3     # bf16 output rounding
+
+
 # ------------------------------------------------------------------------------------------------------ f1: evaluation metrics
 def _metrics_golden():
     import json

@@ -82,6 +82,8 @@ def main():
         if args.nt4 and epi == 0:
             variants.append(('4w', 3, 0, 0))
             variants.append(('4w nt', 3, 0, 2))
+        if args.nt4 and epi == LIN:
+            variants.append(('4w', 3, 0, 0))
         C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
         A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
         descs = {v[0]: make(C[v[0]], A[v[0]]) for v in variants}
