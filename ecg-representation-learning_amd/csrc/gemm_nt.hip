@@ -1097,6 +1097,7 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
     constexpr int F_LIN = ECGVIT_EPI_BIAS | ECGVIT_EPI_RESIDUAL;
     const int fl = d->epilogue;
     if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || d->K < 192 || e.alpha != 1.f || d->scale_a || d->scale_b) return ECGVIT_EINVAL;
+    // (the FFN-down input gradient's body -- x aux, column sums -- measured 1,044 us on this body against 696: 288 B of spills, one wave's VALU)
     if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT)) return ECGVIT_EINVAL;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);

@@ -14,6 +14,9 @@
 // Also here: the column-sum reducer shared with gemm_nt.hip's EPI_COLSUM.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -345,6 +348,180 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad_kernel(ecgvit_gemm_desc d, 
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// gemm_wgrad_kernel_4w: the same items, images, ring, counted waits and epilogue with FOUR waves -- one per SIMD, each owning a 128 x 128
+// block of the tile in 256 accumulator registers (4 x 4 tiles of v_mfma_f32_32x32x16_bf16).  A 16-deep k-step is ONE instruction stream
+// of 16 MFMAs (512 cycles) with the next k-step's 16 transposed fragment reads and four DMA pieces placed between them in a fixed
+// order; 64 instead of 96 fragment reads per k-step and CU, ONE workgroup barrier per K-tile instead of eight (it stands between
+// k-steps 2 and 3: behind it K-tile kt+1 is visible and nobody reads K-tile kt from LDS any more, so B(kt+2) and A(kt+3) may go out).
+// Same MFMA, same K order per accumulator: results are bit-identical to gemm_wgrad_kernel's.
+template <int... X, typename F>
+__device__ __forceinline__ void w4_static_for_impl(std::integer_sequence<int, X...>, F &&f) { (f(std::integral_constant<int, X>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void w4_static_for(F &&f) { w4_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+template <typename TO>
+__global__ __launch_bounds__(256, 1) void gemm_wgrad_kernel_4w(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    const int ntile = tiles_m * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else if (sk.splits > 1) {
+        const int gid = xcd_remap(blockIdx.x, ntile * sk.splits);
+        split = gid / ntile;
+        tid = gid - split * ntile;
+    } else {
+        split = 0;
+        tid = xcd_remap(blockIdx.x, ntile);
+    }
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lda2 = (int)d.lda * 2, ldb2 = (int)d.ldb * 2;
+
+    // DMA: eight 1-KiB pieces of a 32-KiB tile per wave; piece 8*wave + i = k-rows 16*wave + 2*i + {0, 1}: pieces i and i + 4 share the
+    // per-lane offset (same row swizzle), the 8 rows between them go into the scalar offset.  Rows >= kend read as zero (descriptor);
+    // pieces of K-tiles past the slice's end are sent through an EMPTY descriptor instead of around a branch.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)kend * lda2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)kend * ldb2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, 0u, 0x00020000);
+    int voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = 16 * wave + 2 * i + (lane >> 5);
+        const int c = (lane & 31) ^ ((kr & 3) << 2);
+        voA[i] = kr * lda2 + (m0 + c * 8) * 2;
+        voB[i] = kr * ldb2 + (n0 + c * 8) * 2;
+    }
+#define W4_PIECE(RS, VO, LD2, SLOT, K0, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lptr_t)(smem + (SLOT) * TILE_BYTES + (8 * wave + (I)) * 1024), 16, VO[(I) & 3], (K0) * (LD2) + ((I) >> 2) * 8 * (LD2), 0, 0)
+    // fragment reads: lane (g = lane >> 4, i = lane & 15) of the 32 x 16 fragment of 32-column tile t, k-step ks reads 8 bytes at
+    // k = 16 ks + 8 (g >> 1) + (i >> 2) [and k + 4], columns 32 t + 16 (g & 1) + 4 (i & 3) ..: per lane one offset per tile t (the image's row
+    // swizzle folds into the tile index), k-step and the k + 4 half are immediates
+    const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    uint32_t foA[4], foB[4];
+    {
+        const int g = lane >> 4, i = lane & 15;
+        const int base = ((g >> 1) * 8 + (i >> 2)) * 512 + ((g & 1) * 16 + (i & 3) * 4) * 2, sw = (i >> 2) & 3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            foA[t] = sm + base + wm * 256 + ((t ^ sw) << 6);
+            foB[t] = sm + base + wn * 256 + ((t ^ sw) << 6);
+        }
+    }
+    // two fragment buffers (this k-step's and the next one's): lo = k .. k+3 half, hi = k+4 .. half of a lane's 8 k
+    bf16x4 alo[2][4], ahi[2][4], blo[2][4], bhi[2][4];
+#define W4_READ(DST_LO, DST_HI, ADDR, KS)                                                                                    \
+    do {                                                                                                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_LO) : "v"(ADDR), "n"((KS) * 8192) : "memory");         \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST_HI) : "v"(ADDR), "n"((KS) * 8192 + 2048) : "memory");  \
+    } while (0)
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    f32x16 acc[2][4][2];   // [column half][row tile][column tile of the half]: the epilogue drains two 128 x 64 halves
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+    // prologue: A(0), B(0), A(1); behind the barrier the first half of B(1) and the first k-step's fragments
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsA, voA, lda2, 0, kbeg, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsB, voB, ldb2, 3, kbeg, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsA, voA, lda2, 1, kbeg + BK, i);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) W4_PIECE(rsB, voB, ldb2, 4, kbeg + BK, i);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint32_t ab = foA[t], bb = foB[t] + 3 * TILE_BYTES;
+        W4_READ(blo[0][t], bhi[0][t], bb, 0);
+        W4_READ(alo[0][t], ahi[0][t], ab, 0);
+    }
+
+    int ga = 0, gb = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ga1 = ga == 2 ? 0 : ga + 1, ga2 = ga == 0 ? 2 : ga - 1, gb1 = gb ^ 1;
+        const int kB1 = kbeg + (kt + 1) * BK, kA2 = kbeg + (kt + 2) * BK;
+        const bool ok1 = kt + 1 < nk, ok2 = kt + 2 < nk;
+        const __amdgpu_buffer_rsrc_t rB1 = ok1 ? rsB : rs0, rA2 = ok2 ? rsA : rs0, rB2 = ok2 ? rsB : rs0;
+        // one k-step: 16 MFMAs from buffer CUR; the next k-step's 16 reads into buffer CUR ^ 1 (tile bases NA / NB, k-step NKS) behind
+        // MFMAs 0-11 (two each behind the first four: all B fragments, then one A half per MFMA) and four DMA pieces behind MFMAs 2, 6, 10, 14
+#define W4_KSTEP(CUR, NA, NB, NKS, RS, VO, LD2, SLOT, K0, P0)                                                                \
+    do {                                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+        W4_FENCE();                                                                                                          \
+        w4_static_for<16>([&](auto xc_) __attribute__((always_inline)) {                                                     \
+            constexpr int x_ = decltype(xc_)::value, i_ = x_ >> 2, j_ = x_ & 3;                                              \
+            {                                                                                                                \
+                const u32x2 al_ = __builtin_bit_cast(u32x2, alo[CUR][i_]), ah_ = __builtin_bit_cast(u32x2, ahi[CUR][i_]);    \
+                const u32x2 bl_ = __builtin_bit_cast(u32x2, blo[CUR][j_]), bh_ = __builtin_bit_cast(u32x2, bhi[CUR][j_]);    \
+                const u32x4 au_ = {al_[0], al_[1], ah_[0], ah_[1]}, bu_ = {bl_[0], bl_[1], bh_[0], bh_[1]};                   \
+                acc[j_ >> 1][i_][j_ & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, au_), __builtin_bit_cast(bf16x8, bu_), \
+                                                                                  acc[j_ >> 1][i_][j_ & 1], 0, 0, 0);        \
+            }                                                                                                                \
+            W4_FENCE();                                                                                                      \
+            if constexpr (x_ < 4) {                                                                                          \
+                W4_READ(blo[(CUR) ^ 1][x_], bhi[(CUR) ^ 1][x_], (NB)[x_], NKS);                                              \
+                W4_FENCE();                                                                                                  \
+            } else if constexpr (x_ < 12) {                                                                                  \
+                constexpr int t_ = (x_ - 4) >> 1;                                                                            \
+                if constexpr ((x_ & 1) == 0) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[(CUR) ^ 1][t_]) : "v"((NA)[t_]), "n"((NKS) * 8192) : "memory"); \
+                else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[(CUR) ^ 1][t_]) : "v"((NA)[t_]), "n"((NKS) * 8192 + 2048) : "memory"); \
+                W4_FENCE();                                                                                                  \
+            }                                                                                                                \
+            if constexpr ((x_ & 3) == 2) {                                                                                   \
+                W4_PIECE(RS, VO, LD2, SLOT, K0, (P0) + (x_ >> 2));                                                           \
+                W4_FENCE();                                                                                                  \
+            }                                                                                                                \
+        });                                                                                                                  \
+    } while (0)
+        uint32_t ca[4], cb[4], na[4], nb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ca[t] = foA[t] + ga * TILE_BYTES; cb[t] = foB[t] + (3 + gb) * TILE_BYTES;
+            na[t] = foA[t] + ga1 * TILE_BYTES; nb[t] = foB[t] + (3 + gb1) * TILE_BYTES;
+        }
+        W4_KSTEP(0, ca, cb, 1, rB1, voB, ldb2, 3 + gb1, kB1, 4);    // second half of B(kt+1)
+        W4_KSTEP(1, ca, cb, 2, rA2, voA, lda2, ga2, kA2, 0);        // A(kt+2)
+        W4_KSTEP(0, ca, cb, 3, rA2, voA, lda2, ga2, kA2, 4);
+        // the K-tile's one counted wait and one barrier: everything but A(kt+2) has landed; this wave's reads of K-tile kt have retired
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        W4_FENCE();
+        __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+        W4_KSTEP(1, na, nb, 0, rB2, voB, ldb2, 3 + gb, kB1 + BK, 0);   // first half of B(kt+2), into the slot of B(kt); reads of K-tile kt+1
+        ga = ga1; gb = gb1;
+    }
+#undef W4_KSTEP
+#undef W4_READ
+#undef W4_PIECE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+    __builtin_amdgcn_s_barrier();
+#undef W4_FENCE
+    // the epilogue's per-wave LDS patches: one per (wave, column half) -- eight in all, as with eight waves
+    epilogue_store<TO>(acc[0], smem, d, e, sk, split, m0, n0, 4 * wm + 2 * wn, lane);
+    epilogue_store<TO>(acc[1], smem, d, e, sk, split, m0, n0, 4 * wm + 2 * wn + 1, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // The same kernel on 8-BIT operands (fp8_linear; BASELINE.json configs[4]): dW = dY8^T . X8 with dY8 in e5m2 (or e4m3) and X8 in e4m3,
 // both k-major ([token rows][features], one byte per element -- the copies the forward / input-gradient products already own), on the
 // block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (twice the bf16 MFMA rate).  A K-tile is 128 token rows deep in
@@ -593,6 +770,10 @@ int64_t ecgvit_gemm_wgrad_workspace(const ecgvit_gemm_desc *d) {
     return s > 1 ? (int64_t)s * d->M * d->N * 4 : 0;
 }
 
+#ifdef ECGVIT_TOOLS
+static int g_tools_wgrad_8w = 0;
+extern "C" void ecgvit_tools_wgrad_body(int eight_wave) { g_tools_wgrad_8w = eight_wave; }   // tools/wgrad_ab.py: which body the next launches take
+#endif
 // argument validation is done by the caller (ecgvit_gemm_bf16_launch)
 int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     const int tiles_m = d->M / BM, tiles_n = d->N / BN, ntile = tiles_m * tiles_n;
@@ -618,8 +799,19 @@ int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
         if (sk.splits > 1) sk.k_per_split = (((d->K + 127) / 128 + sk.splits - 1) / sk.splits) * 128;
         if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
         else hipLaunchKernelGGL(gemm_wgrad8_kernel<0>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
-    } else if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
-    else hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+    } else {
+        bool four = true;
+#ifdef ECGVIT_TOOLS
+        static const int env8 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();   // A/B: 1 = the eight-wave body
+        four = !(env8 || g_tools_wgrad_8w);
+#endif
+        if (four) {
+            const dim3 block4(256);
+            if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel_4w<bf16_t>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_wgrad_kernel_4w<float>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+        } else if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+    }
     ECGVIT_CHECK_LAUNCH();
     if (sk.splits > 1) {
         const int64_t MN = (int64_t)d->M * d->N;

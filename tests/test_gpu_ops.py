@@ -622,7 +622,7 @@ def test_gemm_bf16_persistent_forward_is_race_free_and_exact():
 
 
 def test_gemm_bf16_four_wave_body_is_race_free_exact_and_equal_to_the_eight_wave_body():
-    """plain bf16 products with K >= 1536 run on gemm_nt_kernel_4w (one wave per SIMD, 128 x 128 per wave, fixed-order k-steps); outputs of
+    """plain bf16 products with K >= 1536 (and the residual launches with K >= 768) run on gemm_nt_kernel_4w (one wave per SIMD, 128 x 128 per wave, fixed-order k-steps); outputs of
     more than 256 MB are stored non-temporally (either body).  Small-integer operands make the result exact: it must EQUAL the integer
     reference on every repeated launch (ragged M and N, one to many tiles per workgroup, K-tile counts 24 to 48), and the chunked launch
     of the same product -- which stays on the eight-wave body -- must give the same bits."""
@@ -650,6 +650,20 @@ def test_gemm_bf16_four_wave_body_is_race_free_exact_and_equal_to_the_eight_wave
     hip.gemm(hip.GEMM_NT, Ad, Bd, C8, M, N, K, K, K, N, tiles_per_workgroup=3)
     assert torch.equal(C4, C8)
     assert rel_err(C4, Ad.double() @ Bd.double().t()) < 4e-3     # bf16 output rounding
+    # the residual launches (bias + residual [+ dropout], K >= 768) take the four-wave body too: same bits as the chunked eight-wave launch
+    for (M, N, K, epi) in ((30011, 776, 768, hip.EPI_BIAS | hip.EPI_RESIDUAL | hip.EPI_DROPOUT), (9000, 768, 3072, hip.EPI_BIAS | hip.EPI_RESIDUAL)):
+        Ad = torch.randn(M, K, generator=g).to(BF16).cuda()
+        Bd = (torch.randn(N, K, generator=g) * 0.05).to(BF16).cuda()
+        bias, res = torch.randn(N, generator=g).cuda(), torch.randn(M, N, generator=g).to(BF16).cuda()
+        outs = []
+        for tpw in (0, 2):
+            C = torch.full((M, N), float('nan'), device='cuda', dtype=BF16)
+            hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N, epilogue=epi, bias=bias, residual=res, ldr=N, dropout_p=0.1 if epi & hip.EPI_DROPOUT else 0.0,
+                     seed=11, tiles_per_workgroup=tpw)
+            outs.append(C)
+        assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
+        if not epi & hip.EPI_DROPOUT:
+            assert rel_err(outs[0], Ad.double() @ Bd.double().t() + bias.double() + res.double()) < 4e-3
 
 
 # ------------------------------------------------------------------------------------------------------ f1: evaluation metrics
