@@ -676,6 +676,155 @@ __global__ __launch_bounds__(512, 2) void gemm_wgrad8_kernel(ecgvit_gemm_desc d,
     epilogue_store<float>(acc, smem, d, e, sk, split, m0, n0, wave, lane);
 }
 
+// gemm_wgrad8_kernel_4w: the 8-bit weight-gradient kernel with FOUR waves (one per SIMD, 128 x 128 per wave in 256 accumulator registers),
+// as gemm_wgrad_kernel_4w is to gemm_wgrad_kernel: a 64-deep k-step is one instruction stream of 16 MFMAs (v_mfma_scale_f32_32x32x64_f8f6f4,
+// 64 cycles each) with the next k-step's 32 transposed reads and eight DMA pieces between them; one barrier per 128-deep K-tile, between its
+// two k-steps.  Bit-identical to gemm_wgrad8_kernel.
+template <int AFMT>
+__global__ __launch_bounds__(256, 1) void gemm_wgrad8_kernel_4w(ecgvit_gemm_desc d, EpiParams e, SplitK2 sk, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char smem[LDS_BYTES];
+    constexpr int BK8 = 128;
+    const int ntile = tiles_m * tiles_n;
+    int split, tid;
+    if (sk.splits > 1 && (sk.splits & 7) == 0) {
+        const int r = sk.splits >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+        split = x + 8 * (q % r);
+        tid = q / r;
+    } else if (sk.splits > 1) {
+        const int gid = xcd_remap(blockIdx.x, ntile * sk.splits);
+        split = gid / ntile;
+        tid = gid - split * ntile;
+    } else {
+        split = 0;
+        tid = xcd_remap(blockIdx.x, ntile);
+    }
+    const int tm = tid / tiles_n, tn = tid - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * sk.k_per_split;
+    const int kend = min(d.K, kbeg + sk.k_per_split);
+    const int nk = (kend - kbeg + BK8 - 1) / BK8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lda1 = (int)d.lda, ldb1 = (int)d.ldb;   // byte pitches
+    if (d.scale_a) e.alpha *= *d.scale_a;
+    if (d.scale_b) e.alpha *= *d.scale_b;
+
+    // DMA: eight 1-KiB pieces (4 k-rows x 256 B) of a 32-KiB tile per wave: piece 8*wave + i = k-rows 32*wave + 4*i + (lane >> 4); pieces i and
+    // i + 4 share the per-lane offset (same swizzle: 16 rows apart), the 16 rows go into the scalar offset
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)kend * lda1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)kend * ldb1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, 0u, 0x00020000);
+    int voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = 32 * wave + 4 * i + (lane >> 4);
+        const int c = (lane & 15) ^ ((kr & 7) << 1);
+        voA[i] = kr * lda1 + m0 + c * 16;
+        voB[i] = kr * ldb1 + n0 + c * 16;
+    }
+#define W4_PIECE(RS, VO, LD1, SLOT, K0, I) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (lptr_t)(smem + (SLOT) * TILE_BYTES + (8 * wave + (I)) * 1024), 16, VO[(I) & 3], (K0) * (LD1) + ((I) >> 2) * 16 * (LD1), 0, 0)
+    const uint32_t sm = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+    uint32_t foA[4], foB[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        foA[t] = sm + frag8_lane_off(wm * 128 + t * 32, lane);
+        foB[t] = sm + frag8_lane_off(wn * 128 + t * 32, lane);
+    }
+    // two fragment buffers; fragment f: 0-3 = B column blocks, 4-7 = A row blocks; four 8-byte transposed reads each
+    u32x2 fr[2][8][4];
+#define W4_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define W4_READ8(BUF, F, T, ADDR, KS) \
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(fr[BUF][F][T]) : "v"(ADDR), "n"((KS) * 16384 + 2048 * (T)) : "memory")
+
+    f32x16 acc[2][4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+    // prologue: A(0), B(0), A(1); behind the barrier B(1) and the first k-step's fragments
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsA, voA, lda1, 0, kbeg, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsB, voB, ldb1, 3, kbeg, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsA, voA, lda1, 1, kbeg + BK8, i);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) W4_PIECE(rsB, voB, ldb1, 4, kbeg + BK8, i);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+        const uint32_t ad = f < 4 ? foB[f & 3] + 3 * TILE_BYTES : foA[f & 3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) W4_READ8(0, f, t, ad, 0);
+    }
+
+    int ga = 0, gb = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ga1 = ga == 2 ? 0 : ga + 1, ga2 = ga == 0 ? 2 : ga - 1, gb1 = gb ^ 1;
+        const int kn = kbeg + (kt + 2) * BK8;
+        const bool ok2 = kt + 2 < nk;
+        const __amdgpu_buffer_rsrc_t rA2 = ok2 ? rsA : rs0, rB2 = ok2 ? rsB : rs0;
+        uint32_t ca[4], cb[4], na[4], nb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ca[t] = foA[t] + ga * TILE_BYTES; cb[t] = foB[t] + (3 + gb) * TILE_BYTES;
+            na[t] = foA[t] + ga1 * TILE_BYTES; nb[t] = foB[t] + (3 + gb1) * TILE_BYTES;
+        }
+        // one k-step: 16 MFMAs from buffer CUR; the next k-step's 32 reads into CUR ^ 1 behind MFMAs 0-11 (three each behind the first
+        // eight, two behind the next four; B fragments first) and eight DMA pieces, one behind every other MFMA
+#define W8_KSTEP(CUR, NA, NB, NKS, RS, VO, LD1, SLOT)                                                                         \
+    do {                                                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                   \
+        W4_FENCE();                                                                                                          \
+        w4_static_for<16>([&](auto xc_) __attribute__((always_inline)) {                                                     \
+            constexpr int x_ = decltype(xc_)::value, i_ = x_ >> 2, j_ = x_ & 3;                                              \
+            {                                                                                                                \
+                const i32x8_t a_ = {(int)fr[CUR][4 + i_][0][0], (int)fr[CUR][4 + i_][0][1], (int)fr[CUR][4 + i_][1][0], (int)fr[CUR][4 + i_][1][1], \
+                                    (int)fr[CUR][4 + i_][2][0], (int)fr[CUR][4 + i_][2][1], (int)fr[CUR][4 + i_][3][0], (int)fr[CUR][4 + i_][3][1]}; \
+                const i32x8_t b_ = {(int)fr[CUR][j_][0][0], (int)fr[CUR][j_][0][1], (int)fr[CUR][j_][1][0], (int)fr[CUR][j_][1][1],   \
+                                    (int)fr[CUR][j_][2][0], (int)fr[CUR][j_][2][1], (int)fr[CUR][j_][3][0], (int)fr[CUR][j_][3][1]};   \
+                acc[j_ >> 1][i_][j_ & 1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, acc[j_ >> 1][i_][j_ & 1], AFMT, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F); \
+            }                                                                                                                \
+            W4_FENCE();                                                                                                      \
+            constexpr int r0_ = x_ < 8 ? 3 * x_ : 24 + 2 * (x_ - 8), nr_ = x_ < 8 ? 3 : x_ < 12 ? 2 : 0;                     \
+            if constexpr (nr_ > 0) { W4_READ8((CUR) ^ 1, (r0_ >> 2), (r0_ & 3), ((r0_ >> 2) < 4 ? (NB)[(r0_ >> 2) & 3] : (NA)[(r0_ >> 2) & 3]), NKS); } \
+            if constexpr (nr_ > 1) { W4_READ8((CUR) ^ 1, ((r0_ + 1) >> 2), ((r0_ + 1) & 3), (((r0_ + 1) >> 2) < 4 ? (NB)[((r0_ + 1) >> 2) & 3] : (NA)[((r0_ + 1) >> 2) & 3]), NKS); } \
+            if constexpr (nr_ > 2) { W4_READ8((CUR) ^ 1, ((r0_ + 2) >> 2), ((r0_ + 2) & 3), (((r0_ + 2) >> 2) < 4 ? (NB)[((r0_ + 2) >> 2) & 3] : (NA)[((r0_ + 2) >> 2) & 3]), NKS); } \
+            if constexpr (nr_ > 0) W4_FENCE();                                                                               \
+            if constexpr ((x_ & 1) == 1) {                                                                                   \
+                W4_PIECE(RS, VO, LD1, SLOT, kn, x_ >> 1);                                                                    \
+                W4_FENCE();                                                                                                  \
+            }                                                                                                                \
+        });                                                                                                                  \
+    } while (0)
+        W8_KSTEP(0, ca, cb, 1, rA2, voA, lda1, ga2);          // A(kt+2) goes out
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        W4_FENCE();
+        __builtin_amdgcn_s_barrier();
+        W4_FENCE();
+        W8_KSTEP(1, na, nb, 0, rB2, voB, ldb1, 3 + gb);       // B(kt+2) into the slot of B(kt); reads of K-tile kt+1
+        ga = ga1; gb = gb1;
+    }
+#undef W8_KSTEP
+#undef W4_READ8
+#undef W4_PIECE
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    W4_FENCE();
+    __builtin_amdgcn_s_barrier();
+#undef W4_FENCE
+    epilogue_store<float>(acc[0], smem, d, e, sk, split, m0, n0, 4 * wm + 2 * wn, lane);
+    epilogue_store<float>(acc[1], smem, d, e, sk, split, m0, n0, 4 * wm + 2 * wn + 1, lane);
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce2_kernel(const float *__restrict__ slabs, int splits, int64_t MN, int N,
                                                              TO *__restrict__ C, int64_t ldc, EpiParams e,
@@ -797,7 +946,16 @@ int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
     if (f8) {
         // 8-bit K-tiles are 128 token rows deep: slice boundaries on multiples of 128
         if (sk.splits > 1) sk.k_per_split = (((d->K + 127) / 128 + sk.splits - 1) / sk.splits) * 128;
-        if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        bool four8 = true;
+#ifdef ECGVIT_TOOLS
+        static const int env88 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();
+        four8 = !(env88 || g_tools_wgrad_8w);
+#endif
+        if (four8) {
+            const dim3 block4(256);
+            if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<1>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<0>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+        } else if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
         else hipLaunchKernelGGL(gemm_wgrad8_kernel<0>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
     } else {
         bool four = true;
