@@ -12,7 +12,7 @@ bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'nt8', 'tn', 'tn8', 'attn', 'attn8'])
+    kind = rng.choice(['nt', 'nt', 'ntlin', 'nt8', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -27,6 +27,20 @@ while time.time() < t_end:
             hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, tiles_per_workgroup=rng.choice([0, 0, 1, 2, 3]))
             if not torch.equal(C, want):
                 bad += 1; print('NT MISMATCH', M, N, K, out_f32, int((C != want).sum()), flush=True)
+        n_nt += 1
+    elif kind == 'ntlin':    # bias + residual on exact operands: the four-wave body (persistent, K >= 768) against the chunked eight-wave launch and the reference
+        M = rng.choice([2048, 4133, 20000, 66000]) + rng.randrange(0, 256)
+        N = rng.choice([256, 520, 768, 776, 2304])
+        K = 64 * rng.randrange(12, 50)
+        A = torch.randint(-3, 4, (M, K), device='cuda').to(bf); B = torch.randint(-3, 4, (N, K), device='cuda').to(bf)
+        bias = torch.randint(-4, 5, (N,), device='cuda').float(); res = torch.randint(-8, 9, (M, N), device='cuda').to(bf)
+        want = (A.float() @ B.float().t() + bias + res.float()).to(bf)
+        C = torch.empty(M, N, device='cuda', dtype=bf)
+        for tpw in (0, 0, 0, 2):
+            C.fill_(float('nan'))
+            hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_RESIDUAL, bias=bias, residual=res, ldr=N, tiles_per_workgroup=tpw)
+            if not torch.equal(C, want):
+                bad += 1; print('NT-LIN MISMATCH', M, N, K, tpw, int((C != want).sum()), flush=True)
         n_nt += 1
     elif kind == 'nt8':      # 8-bit operands (e4m3 x e4m3 / e5m2 x e4m3), small integers: exact
         M = rng.choice([2048, 4133, 20000, 66000, 128256]) + rng.randrange(0, 256)
