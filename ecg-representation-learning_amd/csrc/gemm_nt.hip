@@ -1036,7 +1036,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
         }
     } else if (d->out_dtype == ECGVIT_BF16) {
         if (fl == 0) {
-            // plain products.  K >= 1536 (the QKV and FFN-up input gradients): the four-wave body -- persistent launches only, alpha 1.
+            // plain products.  K >= 1536 (the QKV and FFN-up input gradients): the four-wave body (alpha 1 only).
             // Outputs that do not fit the 256 MB Infinity Cache (QKV forward: 592 MB) are stored non-temporally: written through L2 they
             // evict the operand panels the tile's neighbours are about to re-read (main loop 3,020 -> 2,620 cycles per K-tile, launch
             // -6...-10 %); smaller outputs (197 MB) are absorbed by the cache and nt costs them 2-3 % (profiles/r03_gemm_4w.txt)
@@ -1049,7 +1049,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #else
             const bool use4w = true, use_nt = big_out;
 #endif
-            if (use4w && d->K >= 1536 && tpw == 0 && e.alpha == 1.f && !d->scale_a && !d->scale_b) return ecgvit_gemm_nt4w_launch(d, s, raster_g, use_nt ? 2 : 0);
+            if (use4w && d->K >= 1536 && e.alpha == 1.f && !d->scale_a && !d->scale_b) return ecgvit_gemm_nt4w_launch(d, s, raster_g, use_nt ? 2 : 0);
             if (use_nt) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, false, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
             else NT_LAUNCH(bf16_t, 0);
             ECGVIT_CHECK_LAUNCH();
@@ -1064,7 +1064,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #else
             const bool use4w = true;
 #endif
-            if (use4w && (fl & ~ECGVIT_EPI_DROPOUT) == F_LIN && d->K >= 768 && tpw == 0 && e.alpha == 1.f && !d->scale_a && !d->scale_b)
+            if (use4w && (fl & ~ECGVIT_EPI_DROPOUT) == F_LIN && d->K >= 768 && e.alpha == 1.f && !d->scale_a && !d->scale_b)
                 return ecgvit_gemm_nt4w_launch(d, s, raster_g, 0);
         }
         switch (fl) {
@@ -1090,7 +1090,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     return ECGVIT_OK;
 }
 
-// the four-wave body (bf16 products, plain or bias + residual [+ dropout], alpha 1, persistent grid); diag: 2 = non-temporal output stores (plain); tools build: 1 = stamped
+// the four-wave body (bf16 products, plain or bias + residual [+ dropout], alpha 1; persistent grid or dispatcher-balanced chunks); diag: 2 = non-temporal output stores (plain); tools build: 1 = stamped
 // instantiation with ablate bits (diag >> 2: 1 stores dropped, 2 no epilogue)
 int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g, int diag) {
     const EpiParams e = make_epi(d);
@@ -1101,7 +1101,8 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
     if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT)) return ECGVIT_EINVAL;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);
-    const dim3 grid((unsigned)std::min(ntile, 256)), block(256);
+    const int tpw = d->tiles_per_workgroup;   // > 0: dispatcher-balanced chunks of ~tpw tiles, as in ecgvit_gemm_nt_launch
+    const dim3 grid((unsigned)(tpw > 0 ? std::max(std::min(ntile, 256), (ntile + tpw - 1) / tpw) : std::min(ntile, 256))), block(256);
 #define NT4W_GO(FL, CAUX, ST, AB) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, FL, CAUX, ST>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, AB)
 #ifdef ECGVIT_TOOLS
     if ((diag & 1) && fl == 0) {

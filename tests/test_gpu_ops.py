@@ -624,8 +624,8 @@ def test_gemm_bf16_persistent_forward_is_race_free_and_exact():
 def test_gemm_bf16_four_wave_body_is_race_free_exact_and_equal_to_the_eight_wave_body():
     """plain bf16 products with K >= 1536 (and the residual launches with K >= 768) run on gemm_nt_kernel_4w (one wave per SIMD, 128 x 128 per wave, fixed-order k-steps); outputs of
     more than 256 MB are stored non-temporally (either body).  Small-integer operands make the result exact: it must EQUAL the integer
-    reference on every repeated launch (ragged M and N, one to many tiles per workgroup, K-tile counts 24 to 48), and the chunked launch
-    of the same product -- which stays on the eight-wave body -- must give the same bits."""
+    reference on every repeated launch (ragged M and N, one to many tiles per workgroup, K-tile counts 12 to 48), persistent and as
+    dispatcher-balanced chunks; the f32-output launch of the same product -- which runs on the eight-wave body -- rounds to the same bits."""
     g = torch.Generator().manual_seed(9)
     for (M, N, K) in ((66001, 776, 1536), (9000, 768, 3072), (2259, 2304, 2304), (60011, 2304, 1536), (60011, 2304, 768)):
         A = torch.randint(-3, 4, (M, K), generator=g).float()
@@ -641,16 +641,22 @@ def test_gemm_bf16_four_wave_body_is_race_free_exact_and_equal_to_the_eight_wave
         C.fill_(float('nan'))
         hip.gemm(hip.GEMM_NT, Ad, Bd, C, M, N, K, K, K, N, tiles_per_workgroup=2)
         assert torch.equal(C, ref), (M, N, K, 'chunked')
-    # random operands: the two bodies accumulate in the same order -- identical bits, not just close
+        C32 = torch.full((M, N), float('nan'), device='cuda')
+        hip.gemm(hip.GEMM_NT, Ad, Bd, C32, M, N, K, K, K, N)      # f32 output: eight-wave body
+        assert torch.equal(C32.to(BF16), ref), (M, N, K, 'eight-wave body, f32 output')
+        del C32
+    # random operands: the two bodies accumulate in the same order -- the f32 result of the eight-wave body rounds to the four-wave body's bits
     M, N, K = 20000, 1000, 2304
     Ad = torch.randn(M, K, generator=g).to(BF16).cuda()
     Bd = (torch.randn(N, K, generator=g) * 0.05).to(BF16).cuda()
     C4, C8 = torch.empty(M, N, device='cuda', dtype=BF16), torch.empty(M, N, device='cuda', dtype=BF16)
+    C8f = torch.empty(M, N, device='cuda')
     hip.gemm(hip.GEMM_NT, Ad, Bd, C4, M, N, K, K, K, N)
     hip.gemm(hip.GEMM_NT, Ad, Bd, C8, M, N, K, K, K, N, tiles_per_workgroup=3)
-    assert torch.equal(C4, C8)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C8f, M, N, K, K, K, N)
+    assert torch.equal(C4, C8) and torch.equal(C4, C8f.to(BF16))
     assert rel_err(C4, Ad.double() @ Bd.double().t()) < 4e-3     # bf16 output rounding
-    # the residual launches (bias + residual [+ dropout], K >= 768) take the four-wave body too: same bits as the chunked eight-wave launch
+    # the residual launches (bias + residual [+ dropout], K >= 768) take the four-wave body too: persistent and chunked launches agree bit for bit
     for (M, N, K, epi) in ((30011, 776, 768, hip.EPI_BIAS | hip.EPI_RESIDUAL | hip.EPI_DROPOUT), (9000, 768, 3072, hip.EPI_BIAS | hip.EPI_RESIDUAL)):
         Ad = torch.randn(M, K, generator=g).to(BF16).cuda()
         Bd = (torch.randn(N, K, generator=g) * 0.05).to(BF16).cuda()

@@ -28,7 +28,7 @@ while time.time() < t_end:
             if not torch.equal(C, want):
                 bad += 1; print('NT MISMATCH', M, N, K, out_f32, int((C != want).sum()), flush=True)
         n_nt += 1
-    elif kind == 'ntlin':    # bias + residual on exact operands: the four-wave body (persistent, K >= 768) against the chunked eight-wave launch and the reference
+    elif kind == 'ntlin':    # bias + residual on exact operands: the four-wave body (K >= 768), persistent and chunked, against the reference
         M = rng.choice([2048, 4133, 20000, 66000]) + rng.randrange(0, 256)
         N = rng.choice([256, 520, 768, 776, 2304])
         K = 64 * rng.randrange(12, 50)
