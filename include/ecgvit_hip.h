@@ -109,8 +109,8 @@ int ecgvit_gemm(const ecgvit_gemm_desc *d, void *stream);
 #define ECGVIT_KERNEL_NONE 0        /* the call would return ECGVIT_EINVAL                                   */
 #define ECGVIT_KERNEL_GEMM_F32 1    /* gemm_f32_kernel: exact-f32 MFMA parity path                           */
 #define ECGVIT_KERNEL_GEMM_BF16 2   /* gemm_bf16_kernel: small / ragged bf16 products                        */
-#define ECGVIT_KERNEL_GEMM_NT 3     /* gemm_nt_kernel: persistent 256x256x64 A.B^T (bf16 or 8-bit operands)  */
-#define ECGVIT_KERNEL_GEMM_WGRAD 4  /* gemm_wgrad_kernel: streaming split-K weight gradients                 */
+#define ECGVIT_KERNEL_GEMM_NT 3     /* gemm_nt_kernel / gemm_nt_kernel_4w (its four-wave body: plain K >= 1536, bias + residual K >= 768): persistent 256x256x64 A.B^T (bf16 or 8-bit operands) */
+#define ECGVIT_KERNEL_GEMM_WGRAD 4  /* gemm_wgrad_kernel_4w / gemm_wgrad8_kernel_4w: streaming split-K weight gradients (four-wave bodies) */
 int ecgvit_gemm_kernel(const ecgvit_gemm_desc *d);
 /* bytes of workspace with which the call would use its preferred split-K factor (0 = none needed) */
 int64_t ecgvit_gemm_workspace(const ecgvit_gemm_desc *d);
