@@ -168,7 +168,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
             for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, (CAUX >> 9) & 0xFF);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX & 0xFF);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
         return;
@@ -1015,17 +1015,6 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #define NT_LAUNCH8(FL, OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, FL, false, OPS>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
 #ifdef ECGVIT_TOOLS
     if ((diag & 64) && fl == 0 && d->dtype == ECGVIT_FP8_E4M3) { NT_LAUNCH8(0, 1); ECGVIT_CHECK_LAUNCH(); return ECGVIT_OK; }   // plain fp8 MFMA (A/B)
-    {   // EXPERIMENT: cache policy of the FFN-up forward's two output streams (diag bits 11-12 or ECGVIT_NT_UPNT: 1 = C nt, 2 = aux nt, 3 = both)
-        static const int env_up = [] { const char *e_ = getenv("ECGVIT_NT_UPNT"); return e_ ? atoi(e_) : 0; }();
-        const int up = env_up | ((diag >> 11) & 3);
-        if (up && d->dtype == ECGVIT_BF16 && d->out_dtype == ECGVIT_BF16 && fl == (F_UP | ECGVIT_EPI_DROPOUT)) {
-            if (up == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, false, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
-            else if (up == 2) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, false, 0, 2 << 9>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
-            else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, false, 0, 2 | (2 << 9)>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
-            ECGVIT_CHECK_LAUNCH();
-            return ECGVIT_OK;
-        }
-    }
 #endif
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
         switch (fl) {

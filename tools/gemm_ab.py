@@ -79,9 +79,6 @@ def main():
             if epi == 0:
                 variants.append((f'8w g={g} nt', 2, g, 128 | 512))   # eight-wave body, non-temporal stores
             variants.append((f'shipped g={g}', 2, g, 0))             # what the library's dispatch picks
-            if epi == UP:
-                for u, nm in ((1, 'C nt'), (2, 'aux nt'), (3, 'C+aux nt')):
-                    variants.append((f'8w {nm}', 2, g, u << 11))
         if args.nt4 and epi == 0:
             variants.append(('4w', 3, 0, 0))
             variants.append(('4w nt', 3, 0, 2))
