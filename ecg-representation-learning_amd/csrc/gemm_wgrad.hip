@@ -941,34 +941,33 @@ int ecgvit_gemm_wgrad_launch(const ecgvit_gemm_desc *d, hipStream_t s) {
         }
     }
     const EpiParams e = make_epi(d);
-    const dim3 grid((unsigned)(ntile * sk.splits)), block(512);
+    const dim3 grid((unsigned)(ntile * sk.splits));
+    [[maybe_unused]] const dim3 block(512);   // the eight-wave kernels (tools build)
     const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
     if (f8) {
         // 8-bit K-tiles are 128 token rows deep: slice boundaries on multiples of 128
         if (sk.splits > 1) sk.k_per_split = (((d->K + 127) / 128 + sk.splits - 1) / sk.splits) * 128;
-        bool four8 = true;
-#ifdef ECGVIT_TOOLS
-        static const int env88 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();
-        four8 = !(env88 || g_tools_wgrad_8w);
+        const dim3 block4(256);
+#ifdef ECGVIT_TOOLS   // A/B against the eight-wave kernels (tools/wgrad_ab.py, ECGVIT_WGRAD_8W=1): the shipped library does not carry them
+        static const int env8 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();
+        if (env8 || g_tools_wgrad_8w) {
+            if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_wgrad8_kernel<0>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        } else
 #endif
-        if (four8) {
-            const dim3 block4(256);
-            if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<1>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
-            else hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<0>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
-        } else if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel<1>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
-        else hipLaunchKernelGGL(gemm_wgrad8_kernel<0>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        if (d->dtype == ECGVIT_BF8_E5M2) hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<1>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(gemm_wgrad8_kernel_4w<0>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
     } else {
-        bool four = true;
+        const dim3 block4(256);
 #ifdef ECGVIT_TOOLS
-        static const int env8 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();   // A/B: 1 = the eight-wave body
-        four = !(env8 || g_tools_wgrad_8w);
+        static const int env8 = [] { const char *e_ = getenv("ECGVIT_WGRAD_8W"); return e_ ? atoi(e_) : 0; }();
+        if (env8 || g_tools_wgrad_8w) {
+            if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        } else
 #endif
-        if (four) {
-            const dim3 block4(256);
-            if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel_4w<bf16_t>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
-            else hipLaunchKernelGGL(gemm_wgrad_kernel_4w<float>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
-        } else if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel<bf16_t>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
-        else hipLaunchKernelGGL(gemm_wgrad_kernel<float>, grid, block, 0, s, *d, e, sk, tiles_m, tiles_n);
+        if (d->out_dtype == ECGVIT_BF16) hipLaunchKernelGGL(gemm_wgrad_kernel_4w<bf16_t>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
+        else hipLaunchKernelGGL(gemm_wgrad_kernel_4w<float>, grid, block4, 0, s, *d, e, sk, tiles_m, tiles_n);
     }
     ECGVIT_CHECK_LAUNCH();
     if (sk.splits > 1) {
