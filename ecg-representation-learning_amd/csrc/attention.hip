@@ -134,32 +134,41 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
 // =====================================================================================================
 // Q8 (fp8_linear): additionally out8 = saturate(out as stored / *q8_scale) in e4m3 -- the A operand of the out-projection's 8-bit
 // product, written here instead of by a quantise pass over `out` -- and *q8_amax = max(*q8_amax, max |out|) for the next step's scale
-template <bool DROP, bool Q8 = false>
+// SPLIT (records of more than 256 tokens, e.g. patch 10 -> 501): one workgroup per (record, head, 256-query half); the keys pass through
+// the SAME 64 KiB of images in 256-key windows (the online softmax carries m, l and O across them), so two workgroups still share a CU --
+// with all 501 keys resident (128 KiB) a CU held one workgroup, two waves per SIMD, and this VALU-bound kernel ran at 2/3 of its rate.
+template <bool DROP, bool Q8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                float *__restrict__ lse, int N, int h, float scale,
                                                                uint64_t seed, uint32_t thresh, float inv_keep,
                                                                uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
                                                                float *__restrict__ q8_amax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nkt = (N + 31) >> 5, NK = nkt * 32;
+    const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
     char *Kimg = smem, *Vimg = smem + NK * 128;
-    const int bh = blockIdx.x, b = bh / h, hd = bh - b * h;
+    const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
+    const int bh = SPLIT ? blockIdx.x / nqh : blockIdx.x, qh = SPLIT ? blockIdx.x - bh * nqh : 0;
+    const int b = bh / h, hd = bh - b * h;
     const int d = h * 64;
     const int64_t d3 = 3 * (int64_t)d;
     const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
-    dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
-    dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (!SPLIT) {
+        // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
+        dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
+        dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
 
     const int lr = lane & 31, lh = lane >> 5;
     const float c = scale * 1.44269504088896340736f;
     const RowOff ro = make_row_off(lane);
     const TrOff to = make_tr_off(lane);
-    for (int qb = wave; qb < nkt; qb += 8) {   // 8 waves: one 32-query block each per pass (all of N <= 256 in one pass)
-        const int q = qb * 32 + lr;
+    // SPLIT: exactly one query block per wave (waves past the last block keep the barriers company)
+    for (int qb = SPLIT ? qh * 8 + wave : wave; qb < (SPLIT ? qh * 8 + wave + 1 : nkt); qb += 8) {   // 8 waves: one 32-query block each per pass (all of N <= 256 in one pass)
+        const bool live = !SPLIT || qb < nkt;
+        const int q = live ? qb * 32 + lr : N;
         const int qc = q < N ? q : N - 1;
         bf16x8 qf[4];
 #pragma unroll
@@ -174,12 +183,24 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
         float m = -INFINITY, l = 0.f;
         for (int kt = 0; kt < nkt; ++kt) {
+            if constexpr (SPLIT) {
+                if ((kt & 7) == 0) {   // next 256-key window: everyone is done with the previous one, then its K / V rows replace it
+                    __syncthreads();
+                    const int k0 = kt * 32, nv = min(256, N - k0);
+                    dma_image<8>(Kimg, base + d + (int64_t)k0 * d3, d3, nv, ((nv + 31) >> 5) << 5, wave, lane);
+                    dma_image<8>(Vimg, base + 2 * d + (int64_t)k0 * d3, d3, nv, ((nv + 31) >> 5) << 5, wave, lane);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
+                if (!live) continue;
+            }
+            const int ktl = SPLIT ? kt & 7 : kt;   // tile inside the resident images
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Kimg + kt * 4096, ro.ks[ks]), qf[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Kimg + ktl * 4096, ro.ks[ks]), qf[ks], s, 0, 0, 0);
             if (kt == nkt - 1) {  // only the last tile can hold padded keys
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                 const bf16x8 pf = pack8(s, ss);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(Vimg + kt * 4096 + ss * 2048, to.lo[dt], to.hi[dt]), pf, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(Vimg + ktl * 4096 + ss * 2048, to.lo[dt], to.hi[dt]), pf, o[dt], 0, 0, 0);
             }
         }
         l += __shfl_xor(l, 32, 64);
@@ -1092,8 +1113,9 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
-    dim3 grid((unsigned)(B * h));
-    const size_t lds = (size_t)((N + 31) / 32) * 32 * 128 * 2;
+    const bool split = N > 256;   // two 256-key windows through 64 KiB of images, one workgroup per 256-query half
+    dim3 grid((unsigned)(B * h * (split ? (N + 255) / 256 : 1)));
+    const size_t lds = split ? (size_t)256 * 128 * 2 : (size_t)((N + 31) / 32) * 32 * 128 * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
@@ -1102,9 +1124,12 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
         if (hipFuncSetAttribute((const void *)attn_fwd_bf16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ECGVIT_ELAUNCH;
         attr_set = true;
     }
-#define FWD(DR, Q) hipLaunchKernelGGL((attn_fwd_bf16_kernel<DR, Q>), grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, (uint8_t *)out8, q8_scale, q8_amax)
-    if (out8) { if (th) FWD(true, true); else FWD(false, true); }
-    else { if (th) FWD(true, false); else FWD(false, false); }
+#define FWD(DR, Q, SP) hipLaunchKernelGGL((attn_fwd_bf16_kernel<DR, Q, SP>), grid, dim3(512), lds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, (uint8_t *)out8, q8_scale, q8_amax)
+    if (split) {
+        if (out8) { if (th) FWD(true, true, true); else FWD(false, true, true); }
+        else { if (th) FWD(true, false, true); else FWD(false, false, true); }
+    } else if (out8) { if (th) FWD(true, true, false); else FWD(false, true, false); }
+    else { if (th) FWD(true, false, false); else FWD(false, false, false); }
 #undef FWD
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
