@@ -373,16 +373,20 @@ def test_attention_bf16_fwd_bwd(N):
         assert rel_err(got, ref) < 2e-2, (nm, rel_err(got, ref))
 
 
-def test_attention_bf16_long_forward_501():
-    """forward covers N <= 512 (seq = 500 patches + CLS, the 'large' long-record geometry)"""
-    g = torch.Generator().manual_seed(501)
-    B, h, dh, N = 1, 2, 64, 501
+@pytest.mark.parametrize('N', [501, 257, 300, 512, 449])
+def test_attention_bf16_long_forward_501(N):
+    """forward covers N <= 512 (seq = 500 patches + CLS, the 'large' long-record geometry).  Above 256 tokens a workgroup owns one 256-query half
+    and the keys pass through the LDS images in two 256-key windows: 257 = a second window of ONE key and seven idle waves in the second query
+    half, 300 / 449 = partial last window and partially idle second half, 512 = both full."""
+    g = torch.Generator().manual_seed(N)
+    B, h, dh = 2, 3, 64
     d = h * dh
     qkv = torch.randn(B * N, 3 * d, generator=g).to(BF16)
     out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
     lse = torch.zeros(B * h * N, device='cuda')
     check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, dh, dh ** -0.5, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
     o_ref, lse_ref, _ = _attn_ref(qkv.double(), B, N, h, dh, dh ** -0.5)
+    assert torch.isfinite(out.float()).all()
     assert rel_err(out, o_ref) < 1e-2 and max_err(lse.view(B, h, N), lse_ref) < 2e-3
 
 
