@@ -19,6 +19,7 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes, null
                 (with the reason in `traffic_source`) when the kernel sources changed since that profile was taken.
   masked        (N = 1, default workload) the build's masked pre-train step timed in the same process: value, ms_per_step, roofline.
+  small         (N = 1, default workload) BASELINE.json configs[1]: EcgVit-small bf16, 251 tokens, 256 records: value, ms_per_step, roofline.
   fp8_large     (N = 1, default workload) BASELINE.json configs[4] on one GPU: EcgVit-large / 501 tokens with fp8 Linear operands, and the
                 same step with bf16 operands back to back on the same device (value, ms_per_step, fp8_over_bf16, roofline vs 5 PFLOP/s).
   cpu_baseline  the CPU oracle's train step (torch eager f32, all host cores) on a bounded sample of the same workload.
@@ -40,6 +41,7 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA
 PEAK_F32_TFLOPS = 157.3
+FP8_DESC = ('fp8 Linear operands on the block-scaled fp8 MFMA: e4m3 activations / weights in the forward products, e5m2 gradients x e4m3 weights in the input-gradient products, e5m2 gradients x e4m3 activations in the weight-gradient products (f32 split-K accumulation); attention, LayerNorm, optimiser bf16 / f32')
 
 CONFIGS = {
     # name: (from_defined name | dict of fields, per-GPU batch)
@@ -49,6 +51,14 @@ CONFIGS = {
     'large': ('ecg-vit-large', 256),
     'tiny2': (dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512), 32),
 }
+
+
+def dropout_desc(conf):
+    """dropout as APPLIED: hidden / embedding sites at p rounded to 1/65536; the fused attention kernels draw 8 bits per key, so the
+    attention-probability dropout runs at round(256 p)/256 (0.1 -> 26/256 = 0.1016), kept values rescaled by the exact keep rate"""
+    p, pa = conf.hidden_dropout_prob, conf.attention_probs_dropout_prob
+    t = min(255, int(pa * 256.0 + 0.5)) if pa > 0 else 0
+    return f'dropout {p:g} (hidden / embedding), attention-probability dropout applied at {t}/256 = {t / 256:.4f} (configured {pa:g})'
 
 
 def make_config(E, name, patch, length, dropout):
@@ -147,6 +157,18 @@ def pmc_traffic(kernel_key, args):
     return None, stale or f'none: no counter profile of workload {key} under profiles/'
 
 
+def cpu_model_name():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(conf, seconds_budget=25.0, masked=False):
     """the CPU oracle (torch eager f32 restatement of the reference step) on the host cores, bounded sample (~seconds_budget)"""
     from oracle import vit_oracle as O   # the ONLY place bench.py touches the oracle: the timed CPU baseline
@@ -199,7 +221,7 @@ def cpu_baseline(conf, seconds_budget=25.0, masked=False):
         tr.step(x, y)
         n += 1
     dt = time.perf_counter() - t0
-    return dict(value=b * n / dt, unit='records/s', cores=cores, kind='port',
+    return dict(value=b * n / dt, unit='records/s', cores=cores, kind='port', cpu_model=cpu_model_name(), cores_available=avail,
                 sample=f'{n} full train steps (fwd+BCE+bwd+clip+AdamW, torch eager f32) of the same model on {b} synthetic '
                        f'12x{conf.max_signal_length} records, {cores} threads of {avail} available (fastest of 16/32/64 on a 1-record probe)',
                 tflops=b * n * flops_rec / dt / 1e12)
@@ -221,6 +243,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
     ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
+    ap.add_argument('--no-small', action='store_true', help='skip the nested EcgVit-small measurement (BASELINE.json configs[1])')
     ap.add_argument('--no-fp8-large', action='store_true', help='skip the nested EcgVit-large fp8 / bf16 measurement (BASELINE.json configs[4] on one GPU)')
     ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
     ap.add_argument('--single-rank-collectives', action='store_true',
@@ -241,8 +264,11 @@ def free_port():
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes of this same command (one per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment -- what torch.distributed.run would set), relay rank 0's stdout, fail if any rank fails.
-    Runs BEFORE anything in this process touches the GPU, starts children (never replaces this process image) and returns the exit code."""
+    Runs BEFORE anything in this process touches the GPU, starts children (never replaces this process image) and returns the exit code.
+    Watchdog: every child is polled; the first non-zero exit terminates (then kills) the others at once -- a rank that dies at import,
+    on an EINVAL or out of memory must not leave its peers inside an RCCL rendezvous or collective until the 10-minute NCCL timeout."""
     import subprocess
+    import threading
     n = args.gpus
     env = dict(os.environ)
     env.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
@@ -253,13 +279,38 @@ def self_launch(args):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode(errors='replace'))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # rank 0's pipe never fills while we poll
+    reader.start()
+    rcs = [None] * n
+    failed_first = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad and failed_first is None:
+            failed_first = bad[0]
+            for r, p in enumerate(procs):            # exactly the processes this parent started, by handle
+                if rcs[r] is None:
+                    p.terminate()
+            deadline = time.monotonic() + 5.0
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=max(0.1, deadline - time.monotonic()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    sys.stdout.write((out0[0] if out0 else b'').decode(errors='replace'))
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
-        print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
+        first = f'; rank {failed_first} failed first, the others were terminated' if failed_first is not None and len(bad) > 1 else ''
+        print(f'bench.py: ranks failed (rank, exit code): {bad}{first}', file=sys.stderr)
         return 1
     return 0
 
@@ -302,10 +353,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rank_times = {}
-
     def timed_run(objective, steps, warmup, conf=conf, batch=batch, dtype=dtype, fp8=fp8):
-        """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result)"""
+        """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result, ms per step of every rank)"""
         torch.manual_seed(77)  # identical initial weights on every rank (HipTrainStep broadcasts rank 0's anyway)
         model = E.EcgVit(config=conf, compute_dtype=dtype, fp8_linear=fp8)
         if objective == 'masked':
@@ -347,8 +396,7 @@ def main():
             dt = max(rank_dt)          # MAX over ranks
         final_loss = float(loss)
         step.finish()
-        rank_times[objective] = [1e3 * d / steps for d in rank_dt]
-        return dt, final_loss, (probe.result() if probe else None)
+        return dt, final_loss, (probe.result() if probe else None), [1e3 * d / steps for d in rank_dt]
 
     def roofline_of(r, objective, **over):
         if not r:
@@ -365,18 +413,34 @@ def main():
             'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
         }
 
-    dt, final_loss, pres = timed_run(args.objective, args.steps, args.warmup)
+    dt, final_loss, pres, rank_ms = timed_run(args.objective, args.steps, args.warmup)   # the headline run: its own per-rank times
     masked_line = None
     if args.objective == 'supervised' and world == 1 and args.config == 'base' and not args.no_masked:
         # the build's own masked pre-train objective (absent from the reference: SURVEY 0), driver-timed next to the headline step
         msteps = min(args.steps, 20)
-        mdt, mloss, mres = timed_run('masked', msteps, min(args.warmup, 3))
+        mdt, mloss, mres, _ = timed_run('masked', msteps, min(args.warmup, 3))
         n_patch = conf.max_signal_length // conf.patch_size
         masked_line = {
             'workload': f'EcgVit-{args.config} masked-patch pre-train step (SimMIM-style: 50 % of the {n_patch} patches replaced by a mask token, no CLS, '
-                        f'L1 reconstruction of the masked patches; fwd+loss+bwd+clip+AdamW), dropout {conf.hidden_dropout_prob}, {batch} records/GPU',
+                        f'L1 reconstruction of the masked patches; fwd+loss+bwd+clip+AdamW), {dropout_desc(conf)}, {batch} records/GPU',
             'value': batch * msteps / mdt, 'unit': 'records/s', 'steps': msteps, 'ms_per_step': 1e3 * mdt / msteps, 'final_loss': mloss,
             'roofline': roofline_of(mres, 'masked'),
+        }
+
+    small_line = None
+    if args.objective == 'supervised' and world == 1 and args.config == 'base' and args.dtype == 'bf16' and not args.no_small:
+        # BASELINE.json configs[1]: EcgVit-small, 250 patches (251 tokens), 256 records, driver-timed next to the headline step
+        sconf, sbatch = make_config(E, 'small', args.patch, args.length, args.dropout)
+        ssteps = min(args.steps, 20)
+        sdt, sloss, sres, _ = timed_run('supervised', ssteps, min(args.warmup, 5), conf=sconf, batch=sbatch, dtype=torch.bfloat16, fp8=False)
+        sflops = E.workload.train_flops_per_record(sconf)
+        sv = sbatch * ssteps / sdt
+        small_line = {
+            'workload': f'EcgVit-small supervised BCE train step (fwd+loss+bwd+clip+AdamW), bf16, {dropout_desc(sconf)}, {sbatch} records/GPU x 12 leads x '
+                        f'{sconf.max_signal_length} samples, patch {sconf.patch_size} ({sconf.max_signal_length // sconf.patch_size + 1} tokens)',
+            'value': sv, 'unit': 'records/s', 'steps': ssteps, 'ms_per_step': 1e3 * sdt / ssteps, 'final_loss': sloss,
+            'model_tflops_per_gpu': sv * sflops / 1e12, 'mfma_frac_of_peak': sv * sflops / 1e12 / PEAK_BF16_TFLOPS,
+            'roofline': roofline_of(sres, 'supervised', config='small', batch=sbatch),
         }
 
     fp8_line = None
@@ -390,15 +454,15 @@ def main():
         for tag, f8 in (('bf16', False), ('fp8', True)):
             gc.collect()
             torch.cuda.empty_cache()
-            ldt, lloss, lres = timed_run('supervised', lsteps, lwarm, conf=lconf, batch=lbatch, dtype=torch.bfloat16, fp8=f8)
+            ldt, lloss, lres, _ = timed_run('supervised', lsteps, lwarm, conf=lconf, batch=lbatch, dtype=torch.bfloat16, fp8=f8)
             res[tag] = (ldt, lloss, lres)
         gc.collect()
         torch.cuda.empty_cache()
         lflops = E.workload.train_flops_per_record(lconf)
         v8, v16 = lbatch * lsteps / res['fp8'][0], lbatch * lsteps / res['bf16'][0]
         fp8_line = {
-            'workload': f'EcgVit-large supervised BCE train step, fp8 Linear operands (e4m3 activations / weights, e5m2 gradients on the block-scaled fp8 MFMA; '
-                        f'bf16 weight gradients, attention, LayerNorm), patch 10 ({lconf.max_signal_length // 10 + 1} tokens), dropout {lconf.hidden_dropout_prob}, {lbatch} records/GPU',
+            'workload': f'EcgVit-large supervised BCE train step, {FP8_DESC}; patch 10 ({lconf.max_signal_length // 10 + 1} tokens), '
+                        f'{dropout_desc(lconf)}, {lbatch} records/GPU',
             'value': v8, 'unit': 'records/s', 'steps': lsteps, 'ms_per_step': 1e3 * res['fp8'][0] / lsteps, 'final_loss': res['fp8'][1],
             'bf16_same_config': {'value': v16, 'ms_per_step': 1e3 * res['bf16'][0] / lsteps, 'final_loss': res['bf16'][1]},
             'fp8_over_bf16': v8 / v16,
@@ -414,12 +478,12 @@ def main():
             else f'12-lead ECG records/sec train step, EcgVit-{args.config}',
             'value': value, 'unit': 'records/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype if not fp8 else 'fp8 (e4m3 / e5m2 operands in the block Linears\' forward and input-gradient GEMMs; bf16 weight gradients, attention, LayerNorm)',
+            'dtype': args.dtype if not fp8 else f'fp8 ({FP8_DESC})',
             'data': 'synthetic',
             'config': {
                 'workload': f'EcgVit-{args.config} ' + ('masked-patch pre-train step (SimMIM-style, 50 % of patches masked, L1 recon; fwd+loss+bwd+clip+AdamW'
                             if args.objective == 'masked' else 'supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW') + (
-                            f'{"+RCCL all-reduce" if world > 1 else ""}), dropout {conf.hidden_dropout_prob}, '
+                            f'{"+RCCL all-reduce" if world > 1 else ""}), {dropout_desc(conf)}, '
                             f'{batch} records/GPU x 12 leads x {conf.max_signal_length} samples, patch {conf.patch_size} '
                             f'({conf.max_signal_length // conf.patch_size + (0 if args.objective == "masked" else 1)} tokens), random-init weights, inputs resident in HBM'),
                 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}' + ('+single-rank-collectives' if args.single_rank_collectives else ''),
@@ -428,7 +492,7 @@ def main():
             'final_loss': final_loss,
             'workload_key': workload_key(args), 'kernel_source_sha16': kernel_source_hash(),
             'rccl_ranks': rccl_ranks,   # size of the RCCL process group the step exchanged gradients over (0 = no group: plain single-GPU step)
-            'rank_ms_per_step': rank_times[args.objective],
+            'rank_ms_per_step': rank_ms,   # the headline run's own step time on every rank (max = ms_per_step)
             'model_tflops_per_gpu': value / world * flops_rec / 1e12,
             'mfma_frac_of_peak': value / world * flops_rec / 1e12 / (PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS),
         }
@@ -436,6 +500,8 @@ def main():
             out['roofline'] = roofline_of(pres, args.objective)
         if masked_line:
             out['masked'] = masked_line
+        if small_line:
+            out['small'] = small_line
         if fp8_line:
             out['fp8_large'] = fp8_line
         if not args.no_cpu_baseline and world == 1:

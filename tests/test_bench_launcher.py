@@ -45,6 +45,28 @@ def test_launcher_fails_when_a_rank_fails(tmp_path):
     assert r.returncode != 0 and 'ranks failed' in r.stderr and '(1, 7)' in r.stderr
 
 
+def test_launcher_watchdog_ends_the_surviving_ranks(tmp_path):
+    """a rank that dies after the others have started (they sit in a rendezvous / collective, here: a long sleep) takes the job down
+    within seconds instead of leaving them to a 10-minute collective timeout"""
+    import time
+    t0 = time.monotonic()
+    r = _run_launcher(tmp_path, '''
+        import time as _t
+        rk = int(os.environ['RANK'])
+        open(os.path.join(os.path.dirname(os.path.abspath(__file__)), f'rank{rk}.started'), 'w').write('x')
+        if rk == 2:
+            while len([f for f in os.listdir(os.path.dirname(os.path.abspath(__file__))) if f.endswith('.started')]) < 3:
+                _t.sleep(0.05)           # die only once every peer is up
+            sys.exit(9)
+        print('{"partial": true}', flush=True)
+        _t.sleep(600)                    # stand-in for a rank blocked in a collective
+    ''')
+    dt = time.monotonic() - t0
+    assert r.returncode != 0 and '(2, 9)' in r.stderr and 'failed first' in r.stderr
+    assert dt < 60, dt
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith('.started')) == ['rank0.started', 'rank1.started', 'rank2.started']
+
+
 def test_world_size_mismatch_is_an_error_not_an_assert(tmp_path):
     env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4'], env=env, capture_output=True, text=True, timeout=300)

@@ -139,10 +139,11 @@ def test_bench_self_launcher_single_rank_collectives():
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--single-rank-collectives', '--steps', '3', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-masked', '--no-fp8-large', '--batch', '64'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--no-masked', '--no-small', '--no-fp8-large', '--batch', '64'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out['rccl_ranks'] == 1 and out['n_gpus'] == 1 and len(out['rank_ms_per_step']) == 1
+    assert abs(max(out['rank_ms_per_step']) - out['ms_per_step']) <= 1e-9 * out['ms_per_step']   # the headline run's own per-rank time
     assert out['config']['parallelism'] == 'dp1+single-rank-collectives' and out['value'] > 0
