@@ -16,118 +16,14 @@
 // LDS image for every [row][64 x bf16] tile (128-B rows):  16-B chunk index ^= bitrev3((row>>1)&7)
 //   -> ds_read_b128 row reads (MFMA K-contiguous operand) hit 16 distinct slots per 16-lane group, and
 //   -> ds_read_b64_tr_b16 reads of 4 consecutive rows x 64 B land in the 4 different 64-B quarters of the bank row.
-#include "common.h"
+#include "attn_common.h"
 #include <cstdlib>
 
+// attention_bwd4.hip (tools library only: the four-wave experiment of round 4)
+int ecgvit_attention_bwd4_launch(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h, float scale,
+                                 uint32_t th, float ik, uint64_t seed, hipStream_t stream, void *dqkv8, const float *q8_scale, float *q8_amax);
+
 namespace {
-
-typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-__device__ __forceinline__ int swz3(int row) {
-    const int x = (row >> 1) & 7;
-    return ((x & 1) << 2) | (x & 2) | (x >> 2);
-}
-// slot swizzle of the 64-B-row dS^T image: key bits (1,2,3) -> slot bits (0,2,1)
-__device__ __forceinline__ int dsw(int key) { return ((key >> 1) & 1) | (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1); }
-__device__ __forceinline__ int img_off(int row, int byte) { return row * 128 + ((((byte >> 4) ^ swz3(row)) << 4) | (byte & 15)); }
-
-// stage `rows_pad` rows x 128 B from global (row stride `ld` elements, rows >= nvalid zero-filled) into an image
-template <int NT>
-__device__ __forceinline__ void stage_image(char *img, const bf16_t *__restrict__ g, int64_t ld, int nvalid, int rows_pad) {
-    for (int c = threadIdx.x; c < rows_pad * 8; c += NT) {
-        const int row = c >> 3, ch = c & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < nvalid) v = *reinterpret_cast<const u32x4 *>(g + (int64_t)row * ld + ch * 8);
-        *reinterpret_cast<u32x4 *>(img + img_off(row, ch * 16)) = v;
-    }
-}
-
-// Same image, staged by LDS-DMA (`buffer_load ... lds`): asynchronous, no VGPR round trip, all pieces of all images in flight
-// at once.  One piece = 8 image rows (1 KiB); the swizzle is applied to the per-lane SOURCE chunk; rows >= nvalid fall beyond
-// the descriptor's num_records and read as zero (hardware bounds check).  Caller waits (vmcnt(0)) and barriers.
-typedef __attribute__((address_space(3))) void *lds_void_p;
-template <int NW>
-__device__ __forceinline__ void dma_image(char *img, const bf16_t *g, int64_t ld, int nvalid, int rows_pad, int wave, int lane) {
-    const uint32_t bytes = (uint32_t)(((int64_t)(nvalid - 1) * ld + 64) * 2);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g, 0, bytes, 0x00020000);
-    const int npiece = rows_pad >> 3;
-    for (int j = wave; j < npiece; j += NW) {
-        const int row = j * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ swz3(row);
-        const int voff = (int)(((int64_t)row * ld + chunk * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_p)(img + j * 1024), 16, voff, 0, 0, 0);
-    }
-}
-
-// A/B operand fragment of a 32x32x16 MFMA whose k runs along the image's 64 columns: X[row0 + (lane&31)][16*ks + 8*(lane>>5) + j]
-__device__ __forceinline__ bf16x8 row_frag(const char *img, int row0, int ks, int lane) {
-    return *reinterpret_cast<const bf16x8 *>(img + img_off(row0 + (lane & 31), (ks * 16 + 8 * (lane >> 5)) * 2));
-}
-
-// fragment whose k runs along the image ROWS in the "accumulator order" of a 32x32 tile:
-//   element j of lane (r = lane&31, h = lane>>5)  =  X[row0 + 8*(j>>2) + 4h + (j&3)][col0 + r]
-// (two transposed reads of 4 rows x 16 columns per 16-lane group)
-__device__ __forceinline__ bf16x8 tr_frag32(const char *img, int row0, int col0, int lane) {
-    const int g = lane >> 4, i = lane & 15;
-    const int row = row0 + 4 * (g >> 1) + (i >> 2);
-    const int colb = (col0 + (g & 1) * 16 + (i & 3) * 4) * 2;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + img_off(row, colb)));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img + img_off(row + 8, colb)));
-    bf16x8 o;
-    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2]; o[3] = lo[3];
-    o[4] = hi[0]; o[5] = hi[1]; o[6] = hi[2]; o[7] = hi[3];
-    return o;
-}
-
-// ---- lane-constant address parts.  Every fragment read below starts at a row that is a multiple of 16, and the image
-// swizzle only looks at row bits 1..3, so the swizzled byte offset splits into (uniform row0 * 128) + a per-lane constant
-// computed ONCE per kernel: the inner loops then spend one v_add per base instead of ~12 VALU ops per read.
-struct RowOff { int ks[4]; };        // row_frag: lane row (lane&31), k-step ks
-struct TrOff { int lo[2], hi[2]; };  // tr_frag32: column block dt = 0/1 (32 columns each), first / second (rows + 8) read
-__device__ __forceinline__ RowOff make_row_off(int lane) {
-    RowOff r;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) r.ks[ks] = img_off(lane & 31, (ks * 16 + 8 * (lane >> 5)) * 2);
-    return r;
-}
-__device__ __forceinline__ TrOff make_tr_off(int lane) {
-    TrOff t;
-    const int g = lane >> 4, i = lane & 15;
-    const int row = 4 * (g >> 1) + (i >> 2);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const int colb = (dt * 32 + (g & 1) * 16 + (i & 3) * 4) * 2;
-        t.lo[dt] = img_off(row, colb);
-        t.hi[dt] = img_off(row + 8, colb);
-    }
-    return t;
-}
-__device__ __forceinline__ bf16x8 row_frag_c(const char *img_row0, int off) { return *reinterpret_cast<const bf16x8 *>(img_row0 + off); }
-__device__ __forceinline__ bf16x8 join_halves(bf16x4 a, bf16x4 b) {
-    // two 8-byte halves -> one 16-byte fragment without per-element moves
-    const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
-    u32x4 u;
-    u[0] = ua[0]; u[1] = ua[1]; u[2] = ub[0]; u[3] = ub[1];
-    return __builtin_bit_cast(bf16x8, u);
-}
-__device__ __forceinline__ bf16x8 tr_frag_c(const char *img_row0, int lo, int hi) {
-    const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + lo));
-    const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(img_row0 + hi));
-    return join_halves(a, b);
-}
-
-// pack accumulator registers 8*ss .. 8*ss+7 into the bf16 B-operand fragment: explicit PAIRS (one v_cvt_pk_bf16_f32 per two values;
-// element-wise casts compile to one convert per value plus a v_perm per pair)
-__device__ __forceinline__ bf16x8 pack8(const f32x16 &x, int ss) {
-    typedef float f32x2_p __attribute__((ext_vector_type(2)));
-    u32x4 u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2_p v; v[0] = x[8 * ss + 2 * j]; v[1] = x[8 * ss + 2 * j + 1];
-        u[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-    }
-    return __builtin_bit_cast(bf16x8, u);
-}
 
 // =====================================================================================================
 // forward: online softmax over 32-key tiles (running max / sum per query, O rescaled when the max moves)
@@ -506,29 +402,9 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 //     youngest operations (the slab just issued, the previous dQ store) stay in flight;
 //   * dK / dV leave through per-wave 4-KiB patches in the dS buffers; their stores are still in flight when the next item starts.
 // Math, fragment layouts, dropout indexing and the dQ tile scheme are those of the kernel above.
-__device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit_debug_attn_stamps): per-block cycle stamps, else null
-
-// Transposed LDS read issued as inline asm: hipcc's waitcnt pass cannot see through the builtin whether an LDS-DMA still in flight
-// aliases the read and drains vmcnt(0) in front of it -- fatal for a kernel whose operand stream is never supposed to drain.  The
-// asm form is invisible to that pass; the caller orders it by hand (s_waitcnt lgkmcnt + sched_barrier before the consumer).
-__device__ __forceinline__ bf16x4 tr_read_asm(uint32_t lds_addr) {
-    bf16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
-    return v;
-}
-template <int OFF> __device__ __forceinline__ bf16x4 tr_read_asm_o(uint32_t lds_addr) {   // immediate offset: no address VALU
-    bf16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
-    return v;
-}
-// two f32 -> one dword of two bf16 (v_cvt_pk_bf16_f32): explicit pairs, so every accumulator value is converted exactly once
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-    f32x2_t v; v[0] = a; v[1] = b;
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ uint32_t lds_addr_of(const char *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
+#ifdef ECGVIT_TOOLS
+__device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit_debug_attn_stamps, tools build): per-block cycle stamps, else null
+#endif
 
 // Records longer than 256 tokens (N <= 512, e.g. patch 10 -> 501) run as TWO launches, one per half of the keys: `k0` is the first key
 // of this launch's 256-key window, queries always run over all of N; the second launch adds its dQ to the first one's (ACCUM).
@@ -561,6 +437,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     const int d3 = 3 * d;
     const int nqb = (N + 31) >> 5;
     const float c = scale * 1.44269504088896340736f;
+    const float log2_ik = DROP ? __builtin_log2f(inv_keep) : 0.f;
+    const float inv_ik = 1.0f / inv_keep;
+    // byte-permute selectors of the in-quad transpose of the dropout hash words (ph_V)
+    [[maybe_unused]] const uint32_t sel1 = (threadIdx.x & 1) ? 0x03070105u : 0x06020400u;
+    [[maybe_unused]] const uint32_t sel2 = (threadIdx.x & 2) ? 0x03020706u : 0x05040100u;
     const RowOff ro = make_row_off(lane);
     const TrOff to = make_tr_off(lane);
     const int dq_g = lane >> 4, dq_i = lane & 15;
@@ -635,7 +516,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x114, 0xF, 0xF, true));   // row_shr:4
         acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x112, 0xF, 0xF, true));   // row_shr:2
         acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x111, 0xF, 0xF, true));   // row_shr:1
-        if ((lane & 15) == 15) delta_s[buf * 32 + row] = acc;
+        if ((lane & 15) == 15) delta_s[buf * 32 + row] = acc * inv_ik;   // delta' = delta (1 - p_drop): the probabilities below carry 1 / (1 - p_drop)
     };
 
     int it = blockIdx.x;
@@ -651,7 +532,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         dma_slab(cur, 0, 0);
         dma_slab(cur, 1, 1);
         dma_slab(cur, 2, 2);
-        lse_s[threadIdx.x] = l0 * 1.44269504088896340736f;
+        lse_s[threadIdx.x] = log2_ik - l0 * 1.44269504088896340736f;   // -LSE' = log2(1 / (1 - p_drop)) - LSE log2 e: the exponential returns p / (1 - p_drop)
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -663,13 +544,14 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     // static priority raise for it, no per-phase flips (guide: two waves per SIMD, item 4)
     if (PRIO == 1 && late) __builtin_amdgcn_s_setprio(1);
     if (PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
-    unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
 #ifdef ECGVIT_TOOLS
+    unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
     // tools build only: per-PHASE stamps of the second item, one record per wave group (lane 0 of waves 0 and 4), behind the 768 block
     // records of the buffer: [768 + block][group][query block][phase 0..7 = start, issue, A, V, B+W, C, wait, barrier]
     unsigned long long *pstamps = (g_attn_stamps && (lane == 0) && (wave == 0 || wave == 4)) ? g_attn_stamps + (768 + (int64_t)blockIdx.x) * 128 + (wave >> 2) * 64 : nullptr;
 #define PH_STAMP(QB, IDX) do { if (pstamps && item_no == 1 && (QB) < 8) pstamps[(QB) * 8 + (IDX)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+    unsigned long long *const stamps = nullptr;   // (every stamp below folds away)
 #define PH_STAMP(QB, IDX) do { } while (0)
 #endif
     int item_no = 0;
@@ -732,37 +614,39 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(dOrow, ro.ks[ks]), vf[ks], dp, 0, 0, 0);
             }
         };
+        // Vector work of a block: 9.5 instructions per score element (13.5 until round 3; the kernel is bound by vector-instruction issue,
+        // profiles/r04_valu_rate.txt): the stored -LSE' carries log2(1 / (1 - p_drop)), so the exponential returns p' = p / (1 - p_drop) at once;
+        // P_dropped = keep ? p' : 0 is ONE byte-select compare + ONE select, on a hash word whose bytes were transposed inside the lane quad (the
+        // lane of key byte b hashes query b of the group: 2 DPP moves + 2 byte permutes per FOUR elements put query k's byte at position k);
+        // dS' = P_dropped dP - p' delta' with delta' = delta (1 - p_drop); the factor `scale` is applied to the dQ tile and the dK flush instead
+        // of every element (exact for the power-of-two dh^-1/2).
         auto ph_V = [&](int qb) __attribute__((always_inline)) {
             const float *delta_c = delta_s + ((jj0 + qb) & 1) * 32;
             const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
             const uint32_t hstep = qpitch * ECGVIT_WEYL;
-            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32)) * qpitch + (uint32_t)((mykey + k0) >> 2)) * ECGVIT_WEYL;
-            const uint32_t bsh = (uint32_t)((mykey + k0) & 3) * 8u, lq = (uint32_t)(lane & 3);
+            const uint32_t lq = (uint32_t)(lane & 3);
+            const uint32_t hq0 = seed_mix(seed) + (((uint32_t)cur.bh * (uint32_t)N + (uint32_t)(qb * 32 + 4 * lh) + lq) * qpitch + (uint32_t)((mykey + k0) >> 2)) * ECGVIT_WEYL;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 l4 = *reinterpret_cast<const f32x4 *>(&lse_c[qb * 32 + 8 * g4 + 4 * lh]);
                 const f32x4 d4 = *reinterpret_cast<const f32x4 *>(&delta_c[8 * g4 + 4 * lh]);
-                uint32_t hk[4];
+                [[maybe_unused]] uint32_t X = 0u;
                 if constexpr (DROP) {
-                    const uint32_t mine = pair_finish(hq0 + ((uint32_t)(8 * g4 + 4 * lh) + lq) * hstep);   // query k = lane & 3 of this group
-                    hk[0] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x00, 0xF, 0xF, true);   // quad_perm:[0,0,0,0]
-                    hk[1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x55, 0xF, 0xF, true);
-                    hk[2] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xAA, 0xF, 0xF, true);
-                    hk[3] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xFF, 0xF, 0xF, true);
+                    const uint32_t mine = pair_finish(hq0 + (uint32_t)(8 * g4) * hstep);   // query (lane & 3) of this group, my key quad
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+                    const uint32_t t1 = __builtin_amdgcn_perm(nb, mine, sel1);
+                    const uint32_t nb2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+                    X = __builtin_amdgcn_perm(nb2, t1, sel2);                                                          // byte k = query k's byte of MY key
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * g4 + k;
-                    float p = __builtin_amdgcn_exp2f(s[r] * c - l4[k]);
-                    float g = dp[r];
-                    if constexpr (DROP) {
-                        const float mlt = ((hk[k] >> bsh) & 0xFFu) >= thresh ? inv_keep : 0.f;
-                        g *= mlt;
-                        s[r] = p * mlt;
-                    } else {
-                        s[r] = p;
-                    }
-                    dp[r] = p * (g - d4[k]) * scale;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, l4[k]));
+                    float pd = p;
+                    if constexpr (DROP) pd = ((X >> (8 * k)) & 0xFFu) >= thresh ? p : 0.f;
+                    const float u = p * d4[k];
+                    s[r] = pd;                       // dropped probabilities feed dV
+                    dp[r] = fmaf(pd, dp[r], -u);     // dS / scale
                 }
             }
 #pragma unroll
@@ -869,14 +753,14 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             const int q = qb * 32 + qt * 16 + dq_i;
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)acc[r];
+            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] * scale);   // (dS is carried without `scale`: ph_V)
             const __amdgpu_buffer_rsrc_t rdq = __builtin_amdgcn_make_buffer_rsrc((void *)(dqkv + (int64_t)cur.b * N * d3 + cur.hd * 64), 0, bytes_q, 0x00020000);
             if constexpr (ACCUM) {   // second key window: dQ += (the first launch's dQ, bf16; requested in ph_issue of this block)
                 // leading group and the item's last block: C(qb) runs behind the barrier of the block that requested it (dq_req);
                 // trailing group otherwise: one block later, after the next request went out (dq_prev)
                 const bf16x4 o = __builtin_bit_cast(bf16x4, use_prev ? dq_prev : dq_req);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] + (float)o[r]);
+                for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] * scale + (float)o[r]);
             }
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
             if constexpr ((Q8 & 2) != 0) {
@@ -967,7 +851,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                     for (int g4 = 0; g4 < 4; ++g4) {
                         bf16x4 a;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) a[k] = (bf16_t)(which == 0 ? dKt[dt][4 * g4 + k] : dVt[dt][4 * g4 + k]);
+                        for (int k = 0; k < 4; ++k) a[k] = (bf16_t)(which == 0 ? dKt[dt][4 * g4 + k] * scale : dVt[dt][4 * g4 + k]);
                         *reinterpret_cast<bf16x4 *>(patch + img_off(lr, (dt * 32 + 8 * g4 + 4 * lh) * 2)) = a;
                     }
                 // same-wave LDS operations execute in order: read the rows back (8 rows x 128 B per instruction) and store them
@@ -1005,7 +889,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         // ---- switch to the next item: its K image and LSE row were fetched during query block 1, its V fragments during the drain
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) vf[ks] = vfn[ks];
-        lse_s[(par ^ 1) * NQ + threadIdx.x] = lse_n * 1.44269504088896340736f;
+        lse_s[(par ^ 1) * NQ + threadIdx.x] = log2_ik - lse_n * 1.44269504088896340736f;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                 // patches drained (the next dS write may reuse them); LSE row visible
         par ^= 1;
@@ -1018,6 +902,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     }
 }
 
+#ifdef ECGVIT_TOOLS
 // probe: exact-integer dump of what each lane receives from the fragment helpers (tests pin the layouts with it)
 __global__ __launch_bounds__(64) void probe_kernel(float *out) {
     __shared__ __attribute__((aligned(16))) char img[64 * 128];
@@ -1060,6 +945,7 @@ __global__ __launch_bounds__(64) void probe_kernel(float *out) {
         out[(3 * 64 + lane) * 16 + r] = colcode[r];
     }
 }
+#endif   // ECGVIT_TOOLS (probe)
 
 
 // ---- export of the post-softmax probabilities of the fused path (next row f3): P[bh][q][k] = exp(scale * q.k - lse[bh][q]), rebuilt from
@@ -1094,9 +980,11 @@ extern "C" int ecgvit_tools_attn_variant(int v) { g_tools_attn_variant = v; retu
 
 extern "C" {
 
-int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 768 workgroups x 128 uint64 cycle stamps written by the persistent backward; NULL = off
+#ifdef ECGVIT_TOOLS   // declared in tools/ecgvit_hip_tools.h, exported by build/libecgvit_hip_tools.so only
+int ecgvit_debug_attn_stamps(void *buf) {   // diagnostics: 768 workgroups x 128 uint64 cycle stamps written by the eight-wave persistent backward; NULL = off
     return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &buf, sizeof(buf)) == hipSuccess ? ECGVIT_OK : ECGVIT_ELAUNCH;
 }
+#endif
 
 int ecgvit_attention_probs(const void *qkv, const float *lse, float *probs, int B, int N, int h, int dh, float scale, int dtype, void *stream) {
     if (dtype != ECGVIT_BF16 || dh % 8 || B <= 0 || N <= 0 || h <= 0 || (int64_t)B * h > 65535) return ECGVIT_EINVAL;
@@ -1152,8 +1040,8 @@ static int attention_bwd_args_ok(const void *qkv, const void *out, const void *d
 }
 
 // one (record, head) item per workgroup, all keys of the item on its waves: N <= 256 only.  The shipped backward for short
-// sequences (N <= 128) and the independent implementation the tests hold the persistent kernel against.
-int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+// sequences (N <= 128) and the independent implementation the tests hold the persistent kernel against (exported by the tools library).
+static int attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
                                  int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype) || N > 256) return ECGVIT_EINVAL;
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
@@ -1174,7 +1062,7 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
     if (!attention_bwd_args_ok(qkv, out, dout, dqkv, B, N, h, dh, dtype)) return ECGVIT_EINVAL;
     if (N <= 128 || (int64_t)N * 3 * h * 64 * 2 >= (1ll << 31)) {   // short sequences / 32-bit buffer offsets exhausted
         if (dqkv8) return ECGVIT_EINVAL;   // the one-item kernel has no 8-bit emission: the caller quantises dqkv itself
-        return ecgvit_attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
+        return attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
     }
     if (dqkv8 && (!q8_scale || !q8_amax || reinterpret_cast<uintptr_t>(dqkv8) % 8)) return ECGVIT_EINVAL;
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
@@ -1189,11 +1077,13 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
 // (the emitting variants run the lockstep schedule: the staggered one has no registers left for the conversions -- 256 VGPRs + spills)
 #define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, false, 1, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
+    if (g_tools_attn_variant == -2)   // tools build: the four-wave, one-wave-per-SIMD experiment of round 4 (attention_bwd4.hip; measured, not shipped)
+        return ecgvit_attention_bwd4_launch(qkv, out, dout, lse, dqkv, B, N, h, scale, th, ik, seed, as_stream(stream), dqkv8, q8_scale, q8_amax);
     if (g_tools_attn_variant >= 0 && th && N <= 256 && !dqkv8) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)
         switch (g_tools_attn_variant) {
-            case 0: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 1>), PERS_ARGS(0)); break;   // round-2 kernel
+            case 0: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 1>), PERS_ARGS(0)); break;   // lockstep
             case 1: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 0>), PERS_ARGS(0)); break;
-            case 2: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 1>), PERS_ARGS(0)); break;
+            case 2: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 1>), PERS_ARGS(0)); break;    // what ships
             case 3: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 0>), PERS_ARGS(0)); break;
             case 4: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, true, 2>), PERS_ARGS(0)); break;
             default: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 2>), PERS_ARGS(0)); break;
@@ -1221,6 +1111,7 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
     }
 #undef PERS
 #undef PERS8
+#undef PERS_ARGS
     return ECGVIT_OK;
 }
 
@@ -1235,10 +1126,17 @@ int ecgvit_attention_bwd_q8(const void *qkv, const void *out, const void *dout, 
     return attention_bwd_launch(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, ECGVIT_BF16, stream, dqkv8, q8_scale, q8_amax);
 }
 
+#ifdef ECGVIT_TOOLS   // declared in tools/ecgvit_hip_tools.h, exported by build/libecgvit_hip_tools.so only
 int ecgvit_probe_mfma_layout(float *out, void *stream) {
     hipLaunchKernelGGL(probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), out);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }
+// the one-item-per-workgroup backward as an entry point of its own (N <= 256): the independent implementation tests hold the persistent kernels against
+int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h,
+                                 int dh, float scale, float dropout_p, uint64_t seed, int dtype, void *stream) {
+    return attention_bwd_oneitem(qkv, out, dout, lse, dqkv, B, N, h, dh, scale, dropout_p, seed, dtype, stream);
+}
+#endif
 
 }  // extern "C"

@@ -71,7 +71,6 @@ SIGNATURES = {
     'ecgvit_attention_fwd_q8': (c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P, _P, _P]),
     'ecgvit_attention_bwd': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _I, _P]),
     'ecgvit_attention_bwd_q8': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _P, _P, _P, _P]),
-    'ecgvit_attention_bwd_oneitem': (c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _U, _I, _P]),
     'ecgvit_attention_probs': (c_int, [_P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     'ecgvit_softmax_rows': (c_int, [_P, _L, _I, _L, _P]),
     'ecgvit_softmax_bwd_rows': (c_int, [_P, _P, _L, _I, _L, _F, _P]),
@@ -92,8 +91,6 @@ SIGNATURES = {
     'ecgvit_scatter_rows': (c_int, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
     'ecgvit_l1_loss_fwd_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _L, _I, _P]),
     'ecgvit_eval_counts': (c_int, [_P, _L, _P, _L, _L, _I, _I, _I, _P, _P]),
-    'ecgvit_probe_mfma_layout': (c_int, [_P, _P]),
-    'ecgvit_debug_attn_stamps': (c_int, [_P]),
 }
 
 _lib = None

@@ -213,11 +213,6 @@ int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, con
 int ecgvit_attention_bwd_q8(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
                             int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, void *dqkv8,
                             const float *q8_scale, float *q8_amax, void *stream);
-/* The same backward on the one-(record, head)-per-workgroup kernel (N <= 256; what ecgvit_attention_bwd itself runs for N <= 128):
- * an independent implementation of the same function, exported so that tests can hold the persistent kernel against it. */
-int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
-                                 int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
-                                 void *stream);
 /* export of the fused path's post-softmax probabilities (next row f3; what vit_pytorch's Recorder hooks, reference ecg_vit.py:176-180):
  * probs[B,h,N,N] f32 = exp(scale * q k^T - lse), from the qkv / lse a fused forward left behind. bf16 path only (the f32 path
  * materialises the scores anyway); visualisation-time, not tuned. B*h <= 65535. */
@@ -305,14 +300,6 @@ int ecgvit_l1_loss_fwd_bwd(const void *pred, const void *target, float *loss, vo
  * ------------------------------------------------------------------------------------------------ */
 int ecgvit_eval_counts(const float *scores, int64_t ld_scores, const float *labels, int64_t ld_labels, int64_t B, int K, int from_logits,
                        int with_auc, uint64_t *counts, void *stream);
-
-/* ------------------------------------------------------------------------------------------------
- * probes used by tests to pin hardware fragment layouts with exact integer data
- * ------------------------------------------------------------------------------------------------ */
-int ecgvit_probe_mfma_layout(float *out /* [4][64][16] */, void *stream);
-/* diagnostics: device buffer of 256 x 128 uint64 that the persistent attention backward fills with per-item / per-query-block cycle stamps
- * (tools/attn_stamps.py); NULL switches it off. The only global state in the library, never set by the product path. */
-int ecgvit_debug_attn_stamps(void *buf);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,18 @@ from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import lib, check, ptr, stream
 
 
+def tools_lib():
+    """the TOOLS build of the library (tools/ecgvit_hip_tools.h): test-only entry points -- the fragment-layout probe and the one-item attention
+    backward the persistent kernel is held against.  Built by __graft_entry__.build(); never loaded by the product package."""
+    import os
+    import sys
+    tools_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    if tools_dir not in sys.path:
+        sys.path.insert(0, tools_dir)
+    import toolslib
+    return toolslib.tools_lib()
+
+
 _keepalive = []  # device copies made by dev() stay alive until the test ends (raw pointers are handed to the C-ABI)
 
 

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from hiputil import dev, rel_err, max_err, gelu, gelu_grad, lib, check, ptr, stream, hip
+from hiputil import dev, rel_err, max_err, gelu, gelu_grad, lib, tools_lib, check, ptr, stream, hip
 from oracle import vit_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +16,7 @@ F32, BF16 = torch.float32, torch.bfloat16
 def test_fragment_layout_probe():
     """pins row_frag / tr_frag32 (ds_read_b64_tr_b16) / the 32x32 accumulator map with exact integers"""
     out = torch.zeros(4, 64, 16, device='cuda')
-    check(lib().ecgvit_probe_mfma_layout(ptr(out), stream()), 'probe')
+    check(tools_lib().ecgvit_probe_mfma_layout(ptr(out), stream()), 'probe')
     o = out.cpu().numpy()
     for lane in range(64):
         r, h = lane & 31, lane >> 5
@@ -834,7 +834,7 @@ def test_attention_bwd_persistent_stream(B, h, N, p):
     check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_fwd')
 
     def bwd(persist):
-        fn = lib().ecgvit_attention_bwd if persist else lib().ecgvit_attention_bwd_oneitem
+        fn = lib().ecgvit_attention_bwd if persist else tools_lib().ecgvit_attention_bwd_oneitem
         r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=BF16)
         check(fn(ptr(qd), ptr(out), ptr(dod), ptr(lse), ptr(r), B, N, h, dh, scale, p, 1234, hip.BF16, stream()), 'attn_bwd')
         torch.cuda.synchronize()

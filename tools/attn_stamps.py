@@ -3,7 +3,9 @@
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecg_representation_learning_amd import hip
-from ecg_representation_learning_amd.hip import lib, check, ptr, stream
+from ecg_representation_learning_amd.hip import check, ptr, stream
+from toolslib import tools_lib as lib
+lib().ecgvit_tools_attn_variant(2)   # the eight-wave persistent kernel of round 3 (the stamps live in it)
 B, N, h, dh = 512, 251, 12, 64
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 d = h * dh; bf = torch.bfloat16

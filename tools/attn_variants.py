@@ -5,16 +5,15 @@ import os, sys, ctypes, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from ecg_representation_learning_amd import hip
-hip.use_library(os.path.join(ROOT, 'ecg-representation-learning_amd', 'csrc', 'build', 'libecgvit_hip_tools.so'))
-from ecg_representation_learning_amd.hip import lib, check, ptr, stream
-NAMES = {0: 'lockstep, waves 4-7 raised (round 2)', 1: 'lockstep, no priority', 2: 'staggered, waves 4-7 raised', 3: 'staggered, no priority',
+from ecg_representation_learning_amd.hip import check, ptr, stream
+from toolslib import tools_lib as lib
+NAMES = {-1: "four-wave kernel (shipped)", 0: 'lockstep, waves 4-7 raised (round 2)', 1: 'lockstep, no priority', 2: 'staggered, waves 4-7 raised', 3: 'staggered, no priority',
          4: 'staggered, waves 0-3 raised', 5: 'lockstep, waves 0-3 raised'}
 B, N, h, dh = 512, 251, 12, 64
 d = h * dh; bf = torch.bfloat16
 qkv = torch.randn(B * N, 3 * d, device='cuda').to(bf); out = torch.empty(B * N, d, device='cuda', dtype=bf); do = torch.randn(B * N, d, device='cuda').to(bf)
 lse = torch.empty(B * h * N, device='cuda')
 l = lib()
-l.ecgvit_tools_attn_variant.argtypes = [ctypes.c_int]
 check(l.ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, dh, 0.125, 0.1, 7, hip.BF16, stream()), 'f')
 outs, times = {}, {v: [] for v in NAMES}
 for rnd in range(6):

@@ -6,6 +6,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import lib, check, ptr, stream
+from toolslib import tools_lib
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(1234)
 bf = torch.bfloat16
@@ -116,7 +117,7 @@ while time.time() < t_end:
         check(lib().ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'f')
         res = []
         for pers in (True, True, True, N > 256):   # the one-item kernel covers N <= 256 only
-            fn = lib().ecgvit_attention_bwd if pers else lib().ecgvit_attention_bwd_oneitem
+            fn = lib().ecgvit_attention_bwd if pers else tools_lib().ecgvit_attention_bwd_oneitem
             r = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=bf)
             check(fn(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(r), B, N, h, 64, 0.125, p, 77, hip.BF16, stream()), 'b')
             torch.cuda.synchronize(); res.append(r)
