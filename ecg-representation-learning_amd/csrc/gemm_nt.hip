@@ -169,7 +169,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
             for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
         }
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX & 0xFF);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
         return;
     }
@@ -221,10 +221,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        if constexpr ((CAUX & 0x100) != 0)   // EXPERIMENT: straight from the accumulator layout (16 rows x 4 runs of 16 B per instruction), no lane permute
-            __builtin_amdgcn_raw_buffer_store_b128(out, bf.c, ok ? m * (uint32_t)bf.ldc2 + ncol * 2 : NT_OOB, 0, CAUX & 0xFF);
-        else
-            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, CAUX & 0xFF);
+        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, CAUX);   // CAUX: cache policy of the output stores (2 = nt)
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax, e.flags);
     } else {   // f32 outputs: 32 B per lane stay in the accumulator layout (no train-step launch takes this branch)
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;

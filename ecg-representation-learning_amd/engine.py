@@ -97,8 +97,9 @@ class VitEngine:
                 # the fused attention kernels draw 8 random bits per key: p is applied as round(256 p) / 256 (0.1 -> 0.1016)
                 raise ValueError(f'bf16 fused attention applies dropout in steps of 1/256: hidden_dropout_prob={self.p_hidden} would round '
                                  f'to no dropout; use 0, a value >= 1/512, or compute_dtype=torch.float32 (exact p)')
-        # fp8 Linear operands (BASELINE.json configs[4]): the four block Linears' forward and input-gradient products take e4m3 / e5m2
-        # operands (per-tensor scales, delayed for activations and gradients); weight gradients, attention, LayerNorm stay bf16
+        # fp8 Linear operands (BASELINE.json configs[4]): every product of the four block Linears takes 8-bit operands -- forward e4m3 x e4m3,
+        # input gradients e5m2 gradients x e4m3 weights, weight gradients e5m2 gradients x e4m3 activations with f32 split-K accumulation
+        # (per-tensor scales, delayed for activations and gradients); attention, LayerNorm and the optimiser stay bf16 / f32
         self.fp8 = bool(fp8_linear)
         if self.fp8:
             if dtype != torch.bfloat16:
@@ -449,7 +450,7 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False, training=training)
-        if self.fp8:
+        if self.fp8 and training:   # (an eval forward keeps the scales it finds: a backward pass that is still pending reads them at launch time)
             self.fp8_begin_step()
         pre = 'vit.'
         self._patch_embed(x, B)
@@ -483,7 +484,7 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m, training=training)
-        if self.fp8:
+        if self.fp8 and training:
             self.fp8_begin_step()
         self._patch_embed(x, B)
         check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),

@@ -27,6 +27,26 @@ def test_library_exports_every_declared_symbol():
     assert set(syms) == set(E.hip.SIGNATURES), set(syms) ^ set(E.hip.SIGNATURES)
 
 
+def test_tools_library_exports_what_its_header_declares_and_product_does_not():
+    """tools/ecgvit_hip_tools.h (probes, the one-item attention backward, stamps, A/B switches) lives in build/libecgvit_hip_tools.so only: the
+    product library exports none of it, the product binding names none of it"""
+    src = open(os.path.join(ROOT, 'tools', 'ecgvit_hip_tools.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    tsyms = sorted(set(re.findall(r'\b(ecgvit_[a-z0-9_]+)\s*\(', src)))
+    assert 'ecgvit_probe_mfma_layout' in tsyms and 'ecgvit_attention_bwd_oneitem' in tsyms and 'ecgvit_debug_attn_stamps' in tsyms
+    tools_path = os.path.join(os.path.dirname(E.hip.LIB_PATH), 'csrc', 'build', 'libecgvit_hip_tools.so')
+    if not os.path.exists(tools_path):
+        import __graft_entry__
+        __graft_entry__.build()
+    tl, pl = ctypes.CDLL(tools_path), ctypes.CDLL(E.hip.LIB_PATH)
+    for s_ in tsyms:
+        assert hasattr(tl, s_), f'{s_} declared in tools/ecgvit_hip_tools.h but not exported by the tools library'
+        assert not hasattr(pl, s_), f'{s_} is a tools entry point but the PRODUCT library exports it'
+        assert s_ not in E.hip.SIGNATURES
+    for s_ in declared_symbols():          # the tools library is the product ABI plus the above
+        assert hasattr(tl, s_)
+
+
 def test_version_and_abi():
     l = E.hip.lib()
     assert l.ecgvit_abi_version() == 3

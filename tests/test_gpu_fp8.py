@@ -176,17 +176,75 @@ def test_fp8_large_layer_shape_vs_cpu_oracle():
         hip.gemm = real
     assert len(m8._engine()._f8_seen) == 16, 'the 8-bit Linear path did not run'         # 8 sites x 2 layers
     assert kinds.count((hip.GEMM_TN, hip.BF8_E5M2)) == 8, kinds                           # the 4 weight gradients of both layers ran on 8-bit operands
-    lref = float(o_ref.loss.detach())
-    assert abs(float(o8.loss.detach()) - lref) / lref < 3e-2, (float(o8.loss.detach()), lref)
-    assert float((o8.logits.detach().cpu() - o_ref.logits.detach()).abs().max()) < 0.2
-    gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
-    g8 = torch.cat([p.grad.flatten() for p in m8.parameters()]).double().cpu()
-    assert torch.isfinite(g8).all()
-    cos = float((g8 @ gref) / (g8.norm() * gref.norm()))
-    assert cos > 0.97, cos
-    for (k, p), (_, q) in zip(m8.named_parameters(), ref.named_parameters()):
-        c = float((p.grad.double().cpu().flatten() @ q.grad.double().flatten()) / (p.grad.double().norm().cpu() * q.grad.double().norm() + 1e-30))
-        assert c > 0.90, (k, c)
+
+    def hold_against_oracle(o, tag):
+        lref = float(o_ref.loss.detach())
+        assert abs(float(o.loss.detach()) - lref) / lref < 3e-2, (tag, float(o.loss.detach()), lref)
+        assert float((o.logits.detach().cpu() - o_ref.logits.detach()).abs().max()) < 0.2, tag
+        gref = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+        g8 = torch.cat([p.grad.flatten() for p in m8.parameters()]).double().cpu()
+        assert torch.isfinite(g8).all(), tag
+        cos = float((g8 @ gref) / (g8.norm() * gref.norm()))
+        assert cos > 0.97, (tag, cos)
+        for (k, p), (_, q) in zip(m8.named_parameters(), ref.named_parameters()):
+            c = float((p.grad.double().cpu().flatten() @ q.grad.double().flatten()) / (p.grad.double().norm().cpu() * q.grad.double().norm() + 1e-30))
+            assert c > 0.90, (tag, k, c)
+    hold_against_oracle(o8, 'first pass (first-use scales, quantise passes)')
+
+    # STEADY STATE -- what bench.py times from its second step on: the scales are DELAYED (from the previous pass's amax) and the producers emit
+    # the 8-bit operand copies themselves (LayerNorm forward / backward, the attention kernels, EPI_QUANT_OUT epilogues).  Same weights, same
+    # batch, same oracle, same tolerances; the emitting entry points must actually have run.
+    eng = m8._engine()
+    fired = {'epi_quant_out': 0, 'layernorm_fwd_q8': 0, 'layernorm_bwd_fused_q8': 0, 'attention_fwd_q8': 0, 'attention_bwd_q8': 0, 'scale_update': 0}
+    first_use = {'fp8_amax': 0}
+    l = hip.lib()
+
+    def counting(name, key):
+        fn = getattr(l, name)
+
+        def wrapped(*a):
+            fired[key] += 1
+            return fn(*a)
+        return fn, wrapped
+    saved = {}
+    for name, key in (('ecgvit_layernorm_fwd_q8', 'layernorm_fwd_q8'), ('ecgvit_layernorm_bwd_fused_q8', 'layernorm_bwd_fused_q8'),
+                      ('ecgvit_attention_fwd_q8', 'attention_fwd_q8'), ('ecgvit_attention_bwd_q8', 'attention_bwd_q8'),
+                      ('ecgvit_fp8_scale_update', 'scale_update')):
+        saved[name], w = counting(name, key)
+        setattr(l, name, w)
+    amax_fn = l.ecgvit_fp8_amax
+    saved['ecgvit_fp8_amax'] = amax_fn
+
+    def amax_spy(*a):
+        first_use['fp8_amax'] += 1
+        return amax_fn(*a)
+    l.ecgvit_fp8_amax = amax_spy
+
+    def spy2(layout, *a, **k):
+        if k.get('epilogue', 0) & hip.EPI_QUANT_OUT:
+            fired['epi_quant_out'] += 1
+        return real(layout, *a, **k)
+    hip.gemm = spy2
+    try:
+        for p in m8.parameters():
+            p.grad = None
+        o8s = m8(sample_values=x.cuda(), labels=y.cuda())
+        o8s.loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm = real
+        for name, fn in saved.items():
+            setattr(l, name, fn)
+    assert all(v > 0 for v in fired.values()), fired          # the delayed scale update and every emitting producer ran in this pass
+    assert first_use['fp8_amax'] == 0, first_use              # ... and no site took the first-use (own amax) path again
+    hold_against_oracle(o8s, 'steady state (delayed scales, producers emit the 8-bit copies)')
+    # an eval forward in between does not move the scales a pending backward would read (advisor, round 3)
+    sc = eng.f8_scale.clone()
+    m8.eval()
+    with torch.no_grad():
+        m8(sample_values=x.cuda())
+    m8.train()
+    assert torch.equal(sc, eng.f8_scale)
 
 
 def test_full_large_fp8_configuration_properties():
