@@ -660,27 +660,34 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 qa[2 * dt] = lds_addr_of(Qrow) + to.lo[dt]; qa[2 * dt + 1] = lds_addr_of(Qrow) + to.hi[dt];
                 da[2 * dt] = lds_addr_of(dOrow) + to.lo[dt]; da[2 * dt + 1] = lds_addr_of(dOrow) + to.hi[dt];
             }
-#define TRG(SS)                                                                                                             \
+            // both sub-steps' transposed fragments are requested up front (16 reads; the score / dP accumulators are dead here, their registers
+            // hold them): the first group of MFMAs waits for the first eight only (counted lgkmcnt), the second group's reads land under it --
+            // one exposed LDS round trip per block instead of two (round 4)
+#define TRQ(SS, T)                                                                                                          \
+            T[0] = tr_read_asm_o<SS * 2048>(da[0]); T[1] = tr_read_asm_o<SS * 2048>(da[1]);                                 \
+            T[2] = tr_read_asm_o<SS * 2048>(qa[0]); T[3] = tr_read_asm_o<SS * 2048>(qa[1]);                                 \
+            T[4] = tr_read_asm_o<SS * 2048>(da[2]); T[5] = tr_read_asm_o<SS * 2048>(da[3]);                                 \
+            T[6] = tr_read_asm_o<SS * 2048>(qa[2]); T[7] = tr_read_asm_o<SS * 2048>(qa[3]);
+#define TRM(SS, T, CNT)                                                                                                     \
             {                                                                                                               \
-                bf16x4 t[8];                                                                                                \
-                t[0] = tr_read_asm_o<SS * 2048>(da[0]); t[1] = tr_read_asm_o<SS * 2048>(da[1]);                             \
-                t[2] = tr_read_asm_o<SS * 2048>(qa[0]); t[3] = tr_read_asm_o<SS * 2048>(qa[1]);                             \
-                t[4] = tr_read_asm_o<SS * 2048>(da[2]); t[5] = tr_read_asm_o<SS * 2048>(da[3]);                             \
-                t[6] = tr_read_asm_o<SS * 2048>(qa[2]); t[7] = tr_read_asm_o<SS * 2048>(qa[3]);                             \
                 u32x4 pu, du;                                                                                               \
                 pu[0] = Pk[4 * SS]; pu[1] = Pk[4 * SS + 1]; pu[2] = Pk[4 * SS + 2]; pu[3] = Pk[4 * SS + 3];                 \
                 du[0] = Dk[4 * SS]; du[1] = Dk[4 * SS + 1]; du[2] = Dk[4 * SS + 2]; du[3] = Dk[4 * SS + 3];                 \
                 const bf16x8 pf = __builtin_bit_cast(bf16x8, pu), dsf = __builtin_bit_cast(bf16x8, du);                     \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                                          \
-                dVt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[0], t[1]), pf, dVt[0], 0, 0, 0);             \
-                dKt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[2], t[3]), dsf, dKt[0], 0, 0, 0);            \
-                dVt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[4], t[5]), pf, dVt[1], 0, 0, 0);             \
-                dKt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(t[6], t[7]), dsf, dKt[1], 0, 0, 0);            \
+                dVt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(T[0], T[1]), pf, dVt[0], 0, 0, 0);             \
+                dKt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(T[2], T[3]), dsf, dKt[0], 0, 0, 0);            \
+                dVt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(T[4], T[5]), pf, dVt[1], 0, 0, 0);             \
+                dKt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(T[6], T[7]), dsf, dKt[1], 0, 0, 0);            \
             }
-            TRG(0)
-            TRG(1)
-#undef TRG
+            bf16x4 tA[8], tB[8];
+            TRQ(0, tA)
+            TRQ(1, tB)
+            TRM(0, tA, 8)
+            TRM(1, tB, 0)
+#undef TRQ
+#undef TRM
         };
         auto ph_W = [&](int qb) __attribute__((always_inline)) {
             char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
@@ -736,20 +743,31 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const int aoff = dq_a[qt], boff = dq_b[dhc];
             const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
-#define DQG(HF)                                                                                                              \
-            {                                                                                                                \
-                bf16x4 t[8];                                                                                                 \
-                t[0] = tr_read_asm_o<(2 * HF) * 2048>(sa); t[1] = tr_read_asm_o<(2 * HF) * 2048 + 1024>(sa);                 \
-                t[2] = tr_read_asm_o<(2 * HF) * 4096>(ka); t[3] = tr_read_asm_o<(2 * HF) * 4096 + 2048>(ka);                 \
-                t[4] = tr_read_asm_o<(2 * HF + 1) * 2048>(sa); t[5] = tr_read_asm_o<(2 * HF + 1) * 2048 + 1024>(sa);         \
-                t[6] = tr_read_asm_o<(2 * HF + 1) * 4096>(ka); t[7] = tr_read_asm_o<(2 * HF + 1) * 4096 + 2048>(ka);         \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
-                __builtin_amdgcn_sched_barrier(0);                                                                           \
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[2], t[3]), join_halves(t[0], t[1]), acc, 0, 0, 0); \
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(t[6], t[7]), join_halves(t[4], t[5]), acc, 0, 0, 0); \
-            }
-            DQG(0) DQG(1) DQG(2) DQG(3)
-#undef DQG
+            // the four key-step groups are software-pipelined by one: group h+1's eight transposed reads are in flight while group h's two
+            // MFMAs run (counted lgkmcnt; after the barrier 48+ registers of the block's arithmetic are dead): one exposed LDS round trip
+            // per dQ tile instead of four (round 4)
+#define DQR(HF, T)                                                                                                           \
+            T[0] = tr_read_asm_o<(2 * HF) * 2048>(sa); T[1] = tr_read_asm_o<(2 * HF) * 2048 + 1024>(sa);                     \
+            T[2] = tr_read_asm_o<(2 * HF) * 4096>(ka); T[3] = tr_read_asm_o<(2 * HF) * 4096 + 2048>(ka);                     \
+            T[4] = tr_read_asm_o<(2 * HF + 1) * 2048>(sa); T[5] = tr_read_asm_o<(2 * HF + 1) * 2048 + 1024>(sa);             \
+            T[6] = tr_read_asm_o<(2 * HF + 1) * 4096>(ka); T[7] = tr_read_asm_o<(2 * HF + 1) * 4096 + 2048>(ka);
+#define DQM(T, CNT)                                                                                                          \
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CNT) : "memory");                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                               \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(T[2], T[3]), join_halves(T[0], T[1]), acc, 0, 0, 0);   \
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(T[6], T[7]), join_halves(T[4], T[5]), acc, 0, 0, 0);   \
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x4 tA[8], tB[8];
+            DQR(0, tA)
+            DQR(1, tB)
+            DQM(tA, 8)
+            DQR(2, tA)
+            DQM(tB, 8)
+            DQR(3, tB)
+            DQM(tA, 8)
+            DQM(tB, 0)
+#undef DQR
+#undef DQM
             const int q = qb * 32 + qt * 16 + dq_i;
             bf16x4 v;
 #pragma unroll
@@ -1073,7 +1091,13 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
     // GPU with a collective's kernels is not left with late workgroups a full static share behind (one per CU measured the same alone)
     const dim3 pg((unsigned)(nitems < 768 ? nitems : 768));
 #define PERS_ARGS(K0) pg, dim3(512), 0, as_stream(stream), (const bf16_t *)qkv, (const bf16_t *)out, (const bf16_t *)dout, lse, (bf16_t *)dqkv, N, h, scale, seed, th, ik, nitems, K0
-#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC>), PERS_ARGS(K0))
+#ifndef ATTN_BWD_STAGGER
+#define ATTN_BWD_STAGGER true
+#endif
+#ifndef ATTN_BWD_PRIO
+#define ATTN_BWD_PRIO 1
+#endif
+#define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER, ATTN_BWD_PRIO>), PERS_ARGS(K0))
 // (the emitting variants run the lockstep schedule: the staggered one has no registers left for the conversions -- 256 VGPRs + spills)
 #define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, false, 1, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
