@@ -380,7 +380,7 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
     return ECGVIT_OK;
 }
 
-const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi3"; }
-int ecgvit_abi_version(void) { return 3; }
+const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi4"; }
+int ecgvit_abi_version(void) { return 4; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h)
 
 }  // extern "C"

@@ -43,3 +43,19 @@ def test_check_catches_a_stale_csv(tmp_path):
         json.dump(b, f)
     errors, _ = check_profiles.check(str(tmp_path), verbose=False)
     assert errors and 'apart' in errors[0]
+
+
+def test_check_catches_a_stale_text_table(tmp_path):
+    """round 3's other failure mode: a per-shape table headed "final sources" that was taken before the final kernels"""
+    import json
+    import check_profiles
+    with open(tmp_path / 'r04_bench_line.json', 'w') as f:
+        json.dump(dict(kernel_source_sha16='a' * 16, workload_key='w'), f)
+    with open(tmp_path / 'r04_gemm_shapes.txt', 'w') as f:
+        f.write('per-shape table\nkernel_source_sha16: ' + 'b' * 16 + '\n')
+    errors, _ = check_profiles.check(str(tmp_path), verbose=False)
+    assert errors and 'stale table' in errors[0]
+    with open(tmp_path / 'r04_gemm_shapes.txt', 'w') as f:
+        f.write('per-shape table\nkernel_source_sha16: ' + 'a' * 16 + '\n')
+    errors, n = check_profiles.check(str(tmp_path), verbose=False)
+    assert not errors and n == 1

@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 from ecg_representation_learning_amd import hip  # noqa: E402
 
 
+import bench as _bench  # noqa: E402
+print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 def load(path):
     l = ctypes.CDLL(path)
     for name in ('ecgvit_attention_fwd', 'ecgvit_attention_bwd'):

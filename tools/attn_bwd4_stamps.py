@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import check, ptr, stream
 from toolslib import tools_lib as lib
+import bench as _bench  # noqa: E402
+print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.1
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 251
 B, h, dh = 512, 12, 64

@@ -7,6 +7,8 @@ sys.path.insert(0, ROOT)
 from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import check, ptr, stream
 from toolslib import tools_lib as lib
+import bench as _bench  # noqa: E402
+print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 NAMES = {-2: "four-wave one-wave-per-SIMD experiment", 0: 'lockstep, waves 4-7 raised (round 2)', 1: 'lockstep, no priority', 2: 'staggered, waves 4-7 raised', 3: 'staggered, no priority',
          4: 'staggered, waves 0-3 raised', 5: 'lockstep, waves 0-3 raised'}
 B, N, h, dh = 512, 251, 12, 64

@@ -9,6 +9,9 @@ For every bench line `profiles/rNN_bench_line*.json` that carries `kernel_source
   * a summary with the same `workload_key` and the same source hash must exist, and the roofline fraction recomputed from ITS stats CSV
     (algorithmic FLOPs per launch of the bench line / average nanoseconds of the gemm_nt family / peak) must agree with the bench line's
     `roofline.frac` within 3 % (a profiled pass clocks 2-3 % lower than an unprofiled one: guides/MI355X_MICROARCH.md, DVFS give-back 2).
+For every text table `profiles/rNN_*.txt` of round 4 on that names the sources it was taken on (a header line `kernel_source_sha16: <hash>`):
+  * the hash must be the one of the newest bench line of the same round (`profiles/rNN_bench_line.json`): a table left over from an earlier
+    build of the round fails the check instead of passing as "final" (round 3's r03_gemm_shapes.txt did exactly that).
 Exit code 0 = consistent; prints one line per check."""
 import csv
 import glob
@@ -89,6 +92,29 @@ def check(profiles=None, verbose=True):
             print(f'ok  {name}: roofline.frac {roof["frac"]:.4f} vs {frac:.4f} from {sname} ({tot / calls / 1e3:.1f} us avg over {calls} launches)')
         if roof.get('traffic') is not None and abs(roof['traffic'] - s['kernels']['gemm_nt'].get('hbm_bytes_per_launch', -1)) > 1:
             errors.append(f'{name}: roofline.traffic {roof["traffic"]} is not {sname}\'s gemm_nt hbm_bytes_per_launch')
+    # text tables that name their sources: same hash as the round's bench line
+    for p in sorted(glob.glob(os.path.join(profiles, 'r*_*.txt'))):
+        name = os.path.basename(p)
+        m = re.match(r'r(\d+)_', name)
+        if not m or int(m.group(1)) < 4:
+            continue
+        with open(p) as f:
+            head = f.read(4096)
+        hs = re.findall(r'kernel_source_sha16:\s*([0-9a-f]{16})', head)
+        if not hs:
+            continue
+        line = os.path.join(profiles, f'r{m.group(1)}_bench_line.json')
+        if not os.path.exists(line):
+            errors.append(f'{name}: names sources {hs[0]} but profiles/{os.path.basename(line)} does not exist')
+            continue
+        with open(line) as f:
+            text = f.read()
+        want = json.loads(text[text.index('{'):]).get('kernel_source_sha16')
+        checked += 1
+        if any(h != want for h in hs):
+            errors.append(f'{name}: taken on sources {hs[0]}, the round\'s bench line is on {want} (stale table)')
+        elif verbose:
+            print(f'ok  {name}: same sources as {os.path.basename(line)} ({want})')
     return errors, checked
 
 

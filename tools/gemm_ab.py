@@ -20,6 +20,8 @@ sys.path.insert(0, ROOT)
 import ecg_representation_learning_amd as E  # noqa: E402,F401
 from ecg_representation_learning_amd import hip  # noqa: E402
 hip.use_library(os.path.join(ROOT, 'ecg-representation-learning_amd', 'csrc', 'build', 'libecgvit_hip_tools.so'))   # explicit: the diagnostic build, never the shipped library
+import bench as _bench  # noqa: E402
+print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 from ecg_representation_learning_amd.hip import (EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_DROPOUT, EPI_COLSUM,  # noqa: E402
                                                   EPI_GELU_GRAD_AUX, EPI_MUL_AUX, GEMM_NT)
 

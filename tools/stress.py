@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ecg_representation_learning_amd import hip
 from ecg_representation_learning_amd.hip import lib, check, ptr, stream
 from toolslib import tools_lib
+import bench as _bench  # noqa: E402
+print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(1234)
 bf = torch.bfloat16
