@@ -84,7 +84,8 @@ class GemmProbe:
 
         def gemm(layout, A, B, C, M, N, K, *a, **k):
             # which kernel symbol this call runs on is the LIBRARY's answer (ecgvit_gemm_kernel: its own dispatch, nothing launched)
-            hit = probe.enabled and layout == probe.layout and C.dtype == probe.out_dtype and \
+            # (C is None: an 8-bit product that emits only the 8-bit copy of its bf16-rounded output -- EPI_NO_OUT)
+            hit = probe.enabled and layout == probe.layout and (torch.bfloat16 if C is None else C.dtype) == probe.out_dtype and \
                 probe.hip.gemm_kernel(layout, A, B, C, M, N, K, *a, **k) == probe.hip.KERNEL_GEMM_NT
             f8 = k.get('fp8_format') is not None
             if hit:
@@ -95,7 +96,7 @@ class GemmProbe:
                 e1.record()
                 probe.events.append((e0, e1))
                 probe.flops += 2.0 * M * N * K
-                probe.bytes += (1.0 if f8 else 2.0) * (M * K + N * K) + 2.0 * M * N
+                probe.bytes += (1.0 if f8 else 2.0) * (M * K + N * K) + (1.0 if C is None else 2.0) * M * N
                 probe.n8 += 1 if f8 else 0
         self.hip.gemm = gemm
         import ecg_representation_learning_amd.engine as eng

@@ -176,8 +176,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             if (lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
         }
         if constexpr (Q8) {
-            qmax = wave_max(qmax);
-            if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
+            wave_amax_publish(q8_amax, qmax);
         }
     }
 }
@@ -914,9 +913,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         it = next_it;
         cur = nxt;
     }
-    if constexpr (Q8 != 0) {   // one atomic max per wave and launch (non-negative floats order as integers)
-        qmax = wave_max(qmax);
-        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
+    if constexpr (Q8 != 0) {   // at most one atomic max per wave and launch (common.h: wave_amax_publish)
+        wave_amax_publish(q8_amax, qmax);
     }
 }
 

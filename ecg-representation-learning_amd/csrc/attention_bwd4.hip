@@ -716,8 +716,7 @@ __global__ __launch_bounds__(256) void attn_bwd4_kernel(const bf16_t *__restrict
         nxt = make_item(it + (int)gridDim.x);
     }
     if constexpr (Q8 != 0) {
-        qmax = wave_max(qmax);
-        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
+        wave_amax_publish(q8_amax, qmax);
     }
 #undef B4_QUARTER
 #undef B4_EXP

@@ -66,6 +66,18 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// running absolute maximum of an 8-bit emitting kernel -> *dst (delayed scaling: the next step's scale).  One wave-wide maximum, then an atomic
+// max on ONE address ONLY when the value would raise what is there: same-address atomics retire one per ~8 ns at the L2 channel, and a
+// launch that sends one per wave and tile (49 k in the attention forward at 512 x 12 x 251, 64 k in an FFN-wide product of EcgVit-large) spent
+// 300-400 us of a 200-500 us kernel on them (profiles/r04_amax_atomics.txt).  The guard reads the slot at device scope (past the CU's L1):
+// a stale value can only be too SMALL, which costs an atomic, never skips one that was needed.  Non-negative floats order as integers.
+__device__ __forceinline__ void wave_amax_publish(float *dst, float v) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && v > 0.f) {
+        unsigned int *slot = reinterpret_cast<unsigned int *>(dst);
+        if (__float_as_uint(v) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(v));
+    }
+}
 // sum over a block of NW waves; every thread gets the result. `red` = NW floats of LDS.
 template <int NW> __device__ __forceinline__ float block_sum(float v, float *red) {
     v = wave_sum(v);

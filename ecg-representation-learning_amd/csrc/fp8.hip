@@ -2,7 +2,7 @@
 // e4m3 for activations and weights, e5m2 ("bf8") for the gradients entering the input-gradient products.  x ~= q * scale with
 // scale = amax / FORMAT_MAX; activations and gradients use DELAYED scaling (the scale of step t comes from the amax the quantise
 // pass of step t-1 accumulated; values beyond it saturate), weights are rescaled from their own amax every time the optimiser has
-// rewritten them.  Everything here is HBM-bound elementwise work: 16-B vector loads, one atomic max per wave.
+// rewritten them.  Everything here is HBM-bound elementwise work: 16-B vector loads, at most one atomic max per wave.
 #include "common.h"
 
 namespace {
@@ -12,8 +12,7 @@ constexpr float FP8_E4M3_MAX = 448.f, BF8_E5M2_MAX = 57344.f;
 __device__ __forceinline__ float fmt_max(int fmt) { return fmt == ECGVIT_BF8_E5M2 ? BF8_E5M2_MAX : FP8_E4M3_MAX; }
 
 __device__ __forceinline__ void wave_atomic_max(float *dst, float v) {
-    v = wave_max(v);
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(reinterpret_cast<unsigned int *>(dst), __float_as_uint(v));   // non-negative floats order as integers
+    wave_amax_publish(dst, v);
 }
 
 // segments: table[2*s] = first element (multiple of 16), table[2*s+1] = element count (multiple of 8) of segment s = blockIdx.y; a null table = one

@@ -384,6 +384,12 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route
 // the one dispatch of ecgvit_gemm: executed (route == nullptr) or only asked about (route receives ECGVIT_KERNEL_*)
 static int gemm_dispatch(const ecgvit_gemm_desc *d, void *stream, int *route) {
     if (!d) return ECGVIT_EINVAL;
+    if (d->epilogue & ECGVIT_EPI_NO_OUT) {   // no-output form: the 8-bit A . B^T kernel's emitting FFN-wide bodies only (ecgvit_gemm_nt_applicable holds the list)
+        const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
+        if (!f8 || d->layout != ECGVIT_GEMM_NT || !(d->epilogue & ECGVIT_EPI_QUANT_OUT) || !d->A || !d->B || !d->aux ||
+            (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16)
+            return ECGVIT_EINVAL;
+    }
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         if (!d->colsum_out || !d->workspace || d->batch1 != 1 || d->batch2 != 1) return ECGVIT_EINVAL;
         if (d->dtype == ECGVIT_BF16 && ecgvit_gemm_nt_applicable(d)) return ecgvit_gemm_bf16_launch(d, as_stream(stream), route);   // fused column sums
@@ -408,7 +414,9 @@ static int gemm_dispatch(const ecgvit_gemm_desc *d, void *stream, int *route) {
         return ecgvit_gemm_wgrad_launch(d, as_stream(stream));
     }
     if (d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2) {   // 8-bit operands: the large A . B^T kernel only (no small-shape fallback)
-        if (!d->A || !d->B || !d->C || (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16) return ECGVIT_EINVAL;
+        if (!d->A || !d->B || (!d->C && !(d->epilogue & ECGVIT_EPI_NO_OUT)) ||
+            (reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) % 16)
+            return ECGVIT_EINVAL;
         if ((d->epilogue & ECGVIT_EPI_BIAS) && (!d->bias || reinterpret_cast<uintptr_t>(d->bias) % 16)) return ECGVIT_EINVAL;
         if ((d->epilogue & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX)) && (!d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 16)) return ECGVIT_EINVAL;
         if ((d->epilogue & ECGVIT_EPI_RESIDUAL) && (!d->residual || d->ldr % 8 || reinterpret_cast<uintptr_t>(d->residual) % 16)) return ECGVIT_EINVAL;

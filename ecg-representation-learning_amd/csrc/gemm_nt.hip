@@ -169,7 +169,8 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
             for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
         }
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX);
+        if constexpr (!(FL & ECGVIT_EPI_NO_OUT))   // (NO_OUT: the consumers read the 8-bit copy only)
+            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
         return;
     }
@@ -221,7 +222,8 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, CAUX);   // CAUX: cache policy of the output stores (2 = nt)
+        if constexpr (!(FL >= 0 && (FL & ECGVIT_EPI_NO_OUT)))
+            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, off, 0, CAUX);   // CAUX: cache policy of the output stores (2 = nt)
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax, e.flags);
     } else {   // f32 outputs: 32 B per lane stay in the accumulator layout (no train-step launch takes this branch)
         const uint32_t off = ok ? m * (uint32_t)bf.ldc2 + ncol * 4 : NT_OOB;
@@ -345,9 +347,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc(a1, want_aux), cs + 8, qmax);
         }
     }
-    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // one atomic max per wave and tile (non-negative floats order as integers)
-        qmax = wave_max(qmax);
-        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(d.q8_amax), __float_as_uint(qmax));
+    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // at most one atomic max per wave and tile, only when it raises the slot (common.h: wave_amax_publish)
+        wave_amax_publish(d.q8_amax, qmax);
     }
     if (NT_HAS(ECGVIT_EPI_COLSUM)) {
         // lanes with equal (lane >> 4) hold the same 16 columns: fold the 16 rows, one partial row per (tile row, wm)
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
     NtBufs bf;
     bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * 2;
-    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, (STAMP && (ablate & 1)) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1 (diagnostics): stores dropped
+    bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, ((STAMP && (ablate & 1)) || !d.C) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1 (diagnostics): stores dropped
     bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
     bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
     bf.ldq = (int)d.ldq8;
@@ -958,6 +959,13 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     if ((int64_t)d->M * d->lda * es + 65536 * d->lda >= (1ll << 31) || (int64_t)d->N * d->ldb * es + 65536 * d->ldb >= (1ll << 31)) return false;
     const int64_t esz = d->out_dtype == ECGVIT_BF16 ? 2 : 4, rows = (int64_t)d->M + 256;   // epilogue offsets are 32-bit byte offsets
     if (rows * d->ldc * esz >= (1ll << 31) || rows * d->ldr * 2 >= (1ll << 31) || rows * d->ldaux * 2 >= (1ll << 31)) return false;
+    if (d->epilogue & ECGVIT_EPI_NO_OUT) {   // only the emitting FFN-wide bodies of the 8-bit kernel have a no-output form
+        const int fl = d->epilogue & ~(ECGVIT_EPI_NO_OUT | ECGVIT_EPI_DROPOUT);
+        const int up = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX | ECGVIT_EPI_QUANT_OUT, dh = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM | ECGVIT_EPI_QUANT_OUT;
+        if (!((d->dtype == ECGVIT_FP8_E4M3 && fl == up) || (d->dtype == ECGVIT_BF8_E5M2 && d->epilogue == (dh | ECGVIT_EPI_NO_OUT)))) return false;
+    } else if (!d->C) {
+        return false;
+    }
     if (d->epilogue & ECGVIT_EPI_QUANT_OUT) {
         if (!f8 || !d->q8_out || !d->q8_scale || !d->q8_amax || d->ldq8 % 8 || reinterpret_cast<uintptr_t>(d->q8_out) % 8 ||
             (d->q8_format != ECGVIT_FP8_E4M3 && d->q8_format != ECGVIT_BF8_E5M2) || rows * d->ldq8 >= (1ll << 31))
@@ -1022,6 +1030,8 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT, 3); break;
             case F_UP | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT, 3); break;
             case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT, 3); break;
+            case F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 3); break;
             default: NT_LAUNCH8(-1, 3); break;
         }
     } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
@@ -1029,6 +1039,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case 0: NT_LAUNCH8(0, 4); break;
             case F_DH: NT_LAUNCH8(F_DH, 4); break;
             case F_DH | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT, 4); break;
+            case F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 4); break;
             default: NT_LAUNCH8(-1, 4); break;
         }
     } else if (d->out_dtype == ECGVIT_BF16) {

@@ -380,7 +380,7 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
     return ECGVIT_OK;
 }
 
-const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi4"; }
-int ecgvit_abi_version(void) { return 4; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h)
+const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi5"; }
+int ecgvit_abi_version(void) { return 5; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points
 
 }  // extern "C"

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__
         const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / d) + eps);
 #pragma unroll
         for (int k = 0; k < E; ++k) v[k] = v[k] * rs * gm[k] + bt[k];
-        L::store(y + r * d, lane, v);
+        if (!Q8 || y) L::store(y + r * d, lane, v);   // (Q8: y may be NULL -- every consumer reads the 8-bit copy)
         if constexpr (Q8) {
             uint8_t *row8 = y8 + r * d;
 #pragma unroll
@@ -407,8 +407,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_fit_kernel(const bf16_t *__
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     }
     if constexpr (Q8) {
-        qmax = wave_max(qmax);
-        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
+        wave_amax_publish(q8_amax, qmax);
     }
 }
 
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[8 * L::N16 + k] = (float)(bf16_t)(o[8 * L::N16 + k] * mk[k]);
                 }
-                L::store(dxm + ro, lane, o);
+                if (!Q8 || dxm) L::store(dxm + ro, lane, o);   // (Q8: dxm may be NULL -- the masked gradient leaves as g8 only)
             }
 #pragma unroll
             for (int k = 0; k < E; ++k) ac[k] += o[k];
@@ -508,8 +507,7 @@ __global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel
         }
     }
     if constexpr (Q8) {
-        qmax = wave_max(qmax);
-        if (lane == 0 && qmax > 0.f) atomicMax(reinterpret_cast<unsigned int *>(q8_amax), __float_as_uint(qmax));
+        wave_amax_publish(q8_amax, qmax);
     }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
@@ -751,7 +749,7 @@ static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, cons
                          void *g8 = nullptr, const float *q8_scale = nullptr, float *q8_amax = nullptr) {
     if (g8 && (!extra || !q8_scale || !q8_amax || dtype != ECGVIT_BF16 || !ln_fit(d) || (int64_t)rows * d >= (1ll << 31))) return ECGVIT_EINVAL;
     if (rows <= 0 || d <= 0 || d % 8 != 0 || d > 2048 || !partial) return ECGVIT_EINVAL;
-    if (extra && (!dcolsum || (dropout_p > 0.f && !dxm) || ((int64_t)rows * d) % 2)) return ECGVIT_EINVAL;
+    if (extra && (!dcolsum || (dropout_p > 0.f && !dxm && !g8) || ((int64_t)rows * d) % 2)) return ECGVIT_EINVAL;
     const int grid = ln_bwd_grid(rows);
     const int np = extra ? 3 : 2;
     const size_t lds = (size_t)4 * np * d * 4;

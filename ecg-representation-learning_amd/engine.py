@@ -106,6 +106,13 @@ class VitEngine:
                 raise ValueError('fp8_linear needs the bf16 engine (compute_dtype=torch.bfloat16)')
             if d % 128 or f % 128:
                 raise ValueError(f'fp8_linear needs hidden_size and intermediate_size to be multiples of 128 (got d={d}, f={f})')
+        # fp8_linear, steady state: four bf16 tensors per layer have 8-bit readers ONLY once their producers emit the 8-bit copies -- the
+        # LayerNorm outputs xn1 / xn2 (QKV / FFN-up product + their weight gradients), the FFN-up output hact (FFN-down product + weight
+        # gradient), the FFN-down input gradient dh (FFN-up input + weight gradient) and the dropout-masked gradient dxm of the fused LayerNorm
+        # backward.  They are then not written at all (ECGVIT_EPI_NO_OUT / NULL y / NULL dxm): ~2.9 GB of stores less per EcgVit-large layer at
+        # 256 x 501 tokens.  Needs every reader on its 8-bit kernel: the weight-gradient kernel wants d, f % 256 == 0 and >= 4096 rows.
+        # (False: keep writing them -- tests hold the two modes against each other bit for bit.)
+        self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
         self.B = None
         self._alloc_key = None
         self.T = self.N
@@ -196,17 +203,22 @@ class VitEngine:
         check(l.ecgvit_fp8_quantize(ptr(x), ptr(q), None, 1, count, fmt, ptr(sc), ptr(am), st), 'fp8_quantize')
         return q, sc
 
-    def _emit8(self, kw, site, ld, out=None):
+    def _emit8(self, kw, site, ld, out=None, only8=False):
         """ask an 8-bit product's epilogue to also write the 8-bit copy of its output that the next product (site `site`) consumes --
-        possible once that site has a scale (from the second pass on); `out`: where (default: the q8b scratch); returns True when armed"""
+        possible once that site has a scale (from the second pass on); `out`: where (default: the q8b scratch); only8: the bf16 output has
+        no reader then (EPI_NO_OUT); returns True when armed"""
         if site not in self._f8_seen:
             return False
-        kw['epilogue'] = kw.get('epilogue', 0) | hip.EPI_QUANT_OUT
+        kw['epilogue'] = kw.get('epilogue', 0) | hip.EPI_QUANT_OUT | (hip.EPI_NO_OUT if only8 else 0)
         kw.update(q8_out=out if out is not None else self.act['q8b'], ldq8=ld, q8_scale=self.f8_scale[site:site + 1], q8_amax=self.f8_amax[site:site + 1],
                   q8_format=hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2)
         return True
 
-    def _linear(self, site, A, name, C, M, N, K, a8=None, emit_site=None, emit_to=None, prequant=False, **kw):
+    def _only8(self, M):
+        """the bf16 copies with 8-bit readers only may be left unwritten in a pass over M token rows (see `fp8_drop_dead_bf16`)"""
+        return self.fp8 and self.fp8_drop_dead_bf16 and M >= 4096
+
+    def _linear(self, site, A, name, C, M, N, K, a8=None, emit_site=None, emit_to=None, prequant=False, emit_only8=False, **kw):
         """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow.
         a8: this layer's persistent e4m3 copy of A (written here, or already by A's producer when `prequant`; the weight-gradient
         product of the backward pass reads it again); emit_site / emit_to: the site that consumes C next and its persistent copy
@@ -218,9 +230,10 @@ class VitEngine:
             q, sc = a8, self.f8_scale[site:site + 1]
         else:
             q, sc = self._quant(site, A, M * K, out=a8)
-        emitted = emit_site is not None and self._emit8(kw, emit_site, N, out=emit_to)
+        emitted = emit_site is not None and self._emit8(kw, emit_site, N, out=emit_to, only8=emit_only8)
         mi = self.w8_index[name]
-        self._gemm(GEMM_NT, q, self.W8[name], C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
+        self._gemm(GEMM_NT, q, self.W8[name], None if kw.get('epilogue', 0) & hip.EPI_NO_OUT else C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3,
+                   scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
         return emitted
 
     def transposed_weight_names(self):
@@ -253,15 +266,16 @@ class VitEngine:
             return self.act['q8' if prequant == 'q8' else 'q8b'][:count], self.f8_scale[site:site + 1]
         return self._quant(site, dY, count)
 
-    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, pre=None, **kw):
+    def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, pre=None, emit_only8=False, **kw):
         """dX[M, kin] = dY[M, nout] . W[nout, kin]: on the forward kernel against the transposed shadow when there is one.
-        pre: (8-bit copy of dY, scale) from `_grad8` (fp8_linear).  Returns True when the 8-bit copy of dX was emitted for `emit_site`."""
+        pre: (8-bit copy of dY, scale) from `_grad8` (fp8_linear).  Returns True when the 8-bit copy of dX was emitted for `emit_site`
+        (emit_only8: and dX itself left unwritten)."""
         if self.fp8 and pre is not None and name in self.w8_index:
             q, sc = pre
-            emitted = emit_site is not None and self._emit8(kw, emit_site, kin)
+            emitted = emit_site is not None and self._emit8(kw, emit_site, kin, only8=emit_only8)
             mi = self.w8_index[name]
-            self._gemm(GEMM_NT, q, self.WT8[name], dX, M, kin, nout, nout, nout, kin, fp8_format=hip.BF8_E5M2, scale_a=sc,
-                       scale_b=self.w8_scale[mi:mi + 1], **kw)
+            self._gemm(GEMM_NT, q, self.WT8[name], None if kw.get('epilogue', 0) & hip.EPI_NO_OUT else dX, M, kin, nout, nout, nout, kin,
+                       fp8_format=hip.BF8_E5M2, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
             return emitted
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
@@ -325,7 +339,9 @@ class VitEngine:
         d = self.d
         if (self.fp8 and q8_site is not None and q8_site in self._f8_seen and rows >= 2048 and d % 256 == 0
                 and d // 64 in (4, 8, 12, 16, 24, 32)):
-            check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(g), ptr(b), ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS, ptr(y8 if y8 is not None else self.act['q8']),
+            # (y has 8-bit readers only when it has a persistent 8-bit copy for the weight gradient: see fp8_drop_dead_bf16)
+            check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(g), ptr(b), None if (y8 is not None and self._only8(rows)) else ptr(y), ptr(mean), ptr(rstd), rows, d, LN_EPS,
+                                                ptr(y8 if y8 is not None else self.act['q8']),
                                                 ptr(self.f8_scale[q8_site:q8_site + 1]), ptr(self.f8_amax[q8_site:q8_site + 1]), stream()),
                   'layernorm_fwd_q8')
             return True
@@ -345,7 +361,7 @@ class VitEngine:
         if (self.fp8 and q8_site is not None and q8_site in self._f8_seen and rows >= 2048 and d // 64 in (4, 8, 12, 16, 24, 32) and d % 64 == 0
                 and rows * d < 2 ** 31):
             check(lib().ecgvit_layernorm_bwd_fused_q8(ptr(dy), ptr(x), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db),
-                                                      ptr(self.act['ws']), rows, d, ptr(dxm), ptr(dcolsum), p, seed, ptr(self.act['q8']),
+                                                      ptr(self.act['ws']), rows, d, None if self._only8(rows) else ptr(dxm), ptr(dcolsum), p, seed, ptr(self.act['q8']),
                                                       ptr(self.f8_scale[q8_site:q8_site + 1]), ptr(self.f8_amax[q8_site:q8_site + 1]), stream()),
                   'layernorm_bwd_fused_q8')
             return True
@@ -427,7 +443,7 @@ class VitEngine:
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
             hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, a8=L.get('xn2_8'), emit_site=8 * i + 3,
-                              emit_to=L.get('hact_8'), prequant=q2, epilogue=epi,
+                              emit_to=L.get('hact_8'), prequant=q2, emit_only8=self._only8(M), epilogue=epi,
                               bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
             self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, a8=L.get('hact_8'), prequant=hq, epilogue=epi,
@@ -655,7 +671,7 @@ class VitEngine:
                 epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
-            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, pre=g4,
+            dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, pre=g4, emit_only8=self._only8(M),
                              epilogue=epi, aux=L['hpre'],
                              ldaux=f, dropout_p=pdrop, seed=s0 + 3, workspace=a['ws'], colsum_out=G[lp + '1.fn.net.0.bias'])
             g5 = self._grad8(8 * i + 5, a['dh'], M * f, prequant=bool(dq)) if f8 else None

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # the ONE library a drop
 F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT = 128, 256, 512
+EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT, EPI_NO_OUT = 128, 256, 512, 1024
 
 KERNEL_NONE, KERNEL_GEMM_F32, KERNEL_GEMM_BF16, KERNEL_GEMM_NT, KERNEL_GEMM_WGRAD = 0, 1, 2, 3, 4
 
@@ -157,16 +157,23 @@ def gemm_desc(layout, A, B, C, M, N, K, lda, ldb, ldc, *, epilogue=0, bias=None,
               alpha=1.0, dropout_p=0.0, seed=0, batch=(1, 1), strideA=(0, 0), strideB=(0, 0), strideC=(0, 0), workspace=None,
               a_off=0, b_off=0, c_off=0, colsum_out=None, tiles_per_workgroup=0, fp8_format=None, scale_a=None, scale_b=None, q8_out=None, ldq8=0, q8_scale=None,
               q8_amax=None, q8_format=0):
-    """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices)."""
-    _need_cuda(A, B, C)
+    """Fill an `ecgvit_gemm_desc`. A/B/C are tensors (base pointers); *_off are ELEMENT offsets into them (head / q-k-v column slices).
+    C may be None with EPI_NO_OUT (8-bit emitting FFN-wide products whose consumers read the 8-bit copy only): bf16 is then the output type
+    the 8-bit copy is rounded through."""
+    if C is None:
+        if not epilogue & EPI_NO_OUT:
+            raise ValueError('gemm: C is None without EPI_NO_OUT')
+        _need_cuda(A, B)
+    else:
+        _need_cuda(A, B, C)
     d = GemmDesc()
-    d.layout, d.dtype, d.out_dtype, d.epilogue = layout, (fp8_format if fp8_format is not None else code(A.dtype)), code(C.dtype), epilogue
+    d.layout, d.dtype, d.out_dtype, d.epilogue = layout, (fp8_format if fp8_format is not None else code(A.dtype)), (BF16 if C is None else code(C.dtype)), epilogue
     d.scale_a, d.scale_b = ptr(scale_a), ptr(scale_b)   # device scalars of 8-bit operands (A, B are uint8 tensors then)
     d.q8_out, d.ldq8, d.q8_scale, d.q8_amax, d.q8_format = ptr(q8_out), ldq8, ptr(q8_scale), ptr(q8_amax), q8_format
     d.M, d.N, d.K, d.batch1, d.batch2 = M, N, K, batch[0], batch[1]
     d.A, d.lda, d.strideA1, d.strideA2 = A.data_ptr() + a_off * A.element_size(), lda, strideA[0], strideA[1]
     d.B, d.ldb, d.strideB1, d.strideB2 = B.data_ptr() + b_off * B.element_size(), ldb, strideB[0], strideB[1]
-    d.C, d.ldc, d.strideC1, d.strideC2 = C.data_ptr() + c_off * C.element_size(), ldc, strideC[0], strideC[1]
+    d.C, d.ldc, d.strideC1, d.strideC2 = (None if C is None else C.data_ptr() + c_off * C.element_size()), ldc, strideC[0], strideC[1]
     d.bias, d.residual, d.ldr, d.aux, d.ldaux = ptr(bias), ptr(residual), ldr, ptr(aux), ldaux
     d.alpha, d.dropout_p, d.dropout_seed = alpha, dropout_p, seed
     d.colsum_out = ptr(colsum_out)

@@ -66,6 +66,10 @@ int ecgvit_abi_version(void);
 #define ECGVIT_EPI_QUANT_OUT 512 /* additionally q8_out[m,n] = saturate(C[m,n] as stored / *q8_scale) in q8_format (ECGVIT_FP8_E4M3 | ECGVIT_BF8_E5M2),
                                    *q8_amax = max(*q8_amax, max |C| as stored): the 8-bit copy the next Linear's product consumes, written
                                    by the producer instead of by a separate quantise pass (8-bit A.B^T launches only)                        */
+#define ECGVIT_EPI_NO_OUT 1024  /* with ECGVIT_EPI_QUANT_OUT, on the two FFN-wide emitting bodies of the 8-bit A.B^T kernel (BIAS|GELU|GELU_GRAD_AUX[|DROPOUT] and
+                                   MUL_AUX|COLSUM): C is NOT written (C may be NULL) -- q8_out, *q8_amax, aux and colsum_out are exactly what the same
+                                   call without the flag produces (of the bf16-rounded values C would have held).  For a consumer chain that reads
+                                   only the 8-bit copy: 128 KiB less to store per 256 x 256 tile (ABI 5)                                       */
 #define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
                                    the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
                                    max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */
@@ -156,7 +160,8 @@ int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B
 int ecgvit_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
                          int64_t rows, int d, float eps, int dtype, void *stream);
 /* fp8 operand path: the same forward (bf16, d in 64 * {4, 8, 12, 16, 24, 32}) that also writes y8 = saturate(y / *q8_scale) in e4m3 and
- * accumulates *q8_amax = max(*q8_amax, max |y|): the 8-bit operand of the next Linear's product, without a quantise pass over y */
+ * accumulates *q8_amax = max(*q8_amax, max |y|): the 8-bit operand of the next Linear's product, without a quantise pass over y.
+ * y may be NULL (ABI 5): only y8 / mean / rstd are written -- for a step in which every consumer of y reads the 8-bit copy */
 int ecgvit_layernorm_fwd_q8(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd,
                             int64_t rows, int d, float eps, void *y8, const float *q8_scale, float *q8_amax, void *stream);
 /* dx = (dres ? dres : 0) + LN'(dy) ; dgamma/dbeta are OVERWRITTEN with the full reduction over rows.
@@ -175,7 +180,8 @@ int ecgvit_layernorm_bwd_fused(const void *dy, const void *x, const float *gamma
 
 /* fp8 operand path: the same fused backward (bf16, d in 64 * {4, 8, 12, 16, 24, 32}) that also writes g8 = saturate(v / *q8_scale) in e5m2 for
  * v = the gradient the next stage consumes (dxm when dropout_p > 0, else dx; as stored) and accumulates *q8_amax = max(*q8_amax, max |v|):
- * the 8-bit A operand of that stage's input-gradient product, without a quantise pass over the gradient */
+ * the 8-bit A operand of that stage's input-gradient product, without a quantise pass over the gradient.
+ * dxm may be NULL even with dropout_p > 0 (ABI 5): the masked gradient is then written as g8 only (dcolsum and g8 are unchanged) */
 int ecgvit_layernorm_bwd_fused_q8(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd,
                                   const void *dres, void *dx, float *dgamma, float *dbeta, void *partial, int64_t rows, int d,
                                   void *dxm, float *dcolsum, float dropout_p, uint64_t seed, void *g8, const float *q8_scale,

@@ -373,3 +373,132 @@ def test_attention_kernels_emit_their_8bit_copies(N, p):
     assert float(same.float().mean()) > 0.9999, float(same.float().mean())
     # short sequences run the one-item kernel, which does not emit: the entry point says so instead of leaving the copy unwritten
     assert lib().ecgvit_attention_bwd_q8(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dq2), 2, 100, h, dh, 0.125, p, 7, ptr(dq8), ptr(s_dq), ptr(amax), stream()) == 1
+
+
+def test_no_output_forms_emit_exactly_what_the_writing_forms_emit():
+    """ABI 5: ECGVIT_EPI_NO_OUT on the two FFN-wide emitting bodies of the 8-bit A.B^T kernel, y == NULL in ecgvit_layernorm_fwd_q8 and
+    dxm == NULL in ecgvit_layernorm_bwd_fused_q8 leave one bf16 tensor unwritten and change nothing else: the 8-bit copy, its amax, the saved
+    GELU' x mask tensor, the column sums, dx, mean / rstd are bit for bit those of the writing call.  Other epilogues refuse the flag."""
+    M, N, K = 5003, 1024, 512      # ragged last row tile
+    g = torch.Generator().manual_seed(31)
+    A = _rand8((M, K), torch.float8_e4m3fn, g).cuda()
+    Bw = _rand8((N, K), torch.float8_e4m3fn, g, 0.2).cuda()
+    s = torch.tensor([0.5], device='cuda')
+    bias = torch.randn(N, generator=g).cuda()
+    qs = torch.tensor([0.01], device='cuda')
+    UP = hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX | hip.EPI_QUANT_OUT
+
+    def up(no_out, drop):
+        C = torch.full((M, N), 7.0, device='cuda', dtype=BF16)
+        aux = torch.zeros(M, N, device='cuda', dtype=BF16)
+        q8 = torch.full((M, N), 0x7F, dtype=torch.uint8, device='cuda')
+        am = torch.zeros(1, device='cuda')
+        hip.gemm(hip.GEMM_NT, A.view(torch.uint8), Bw.view(torch.uint8), None if no_out else C, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=s, scale_b=s,
+                 epilogue=UP | (hip.EPI_DROPOUT if drop else 0) | (hip.EPI_NO_OUT if no_out else 0), bias=bias, aux=aux, ldaux=N,
+                 dropout_p=0.1 if drop else 0.0, seed=99, q8_out=q8, ldq8=N, q8_scale=qs, q8_amax=am, q8_format=hip.FP8_E4M3)
+        torch.cuda.synchronize()
+        return C, aux, q8, am
+    for drop in (False, True):
+        C0, aux0, q0, am0 = up(False, drop)
+        C1, aux1, q1, am1 = up(True, drop)
+        assert torch.equal(aux0, aux1) and torch.equal(q0, q1) and torch.equal(am0, am1) and float(am0) > 0
+        assert bool((q0 != 0x7F).any()) and not bool((C0 == 7.0).all())
+    # the FFN-down input gradient's body: x saved tensor + column sums, e5m2 gradients x e4m3 weights, e5m2 copy
+    G8 = _rand8((M, K), torch.float8_e5m2, g).cuda()
+    auxin = (torch.rand(M, N, generator=g) * 1.2).to(BF16).cuda()
+    ws = torch.empty(max(lib().ecgvit_colsum_workspace(M, N), 8 * ((M + 255) // 256) * N), dtype=torch.uint8, device='cuda')
+    DH = hip.EPI_MUL_AUX | hip.EPI_COLSUM | hip.EPI_QUANT_OUT
+
+    def dh(no_out):
+        C = torch.full((M, N), 7.0, device='cuda', dtype=BF16)
+        q8 = torch.full((M, N), 0x7F, dtype=torch.uint8, device='cuda')
+        am, cs = torch.zeros(1, device='cuda'), torch.zeros(N, device='cuda')
+        hip.gemm(hip.GEMM_NT, G8.view(torch.uint8), Bw.view(torch.uint8), None if no_out else C, M, N, K, K, K, N, fp8_format=hip.BF8_E5M2, scale_a=s, scale_b=s,
+                 epilogue=DH | (hip.EPI_NO_OUT if no_out else 0), aux=auxin, ldaux=N, workspace=ws, colsum_out=cs,
+                 q8_out=q8, ldq8=N, q8_scale=qs, q8_amax=am, q8_format=hip.BF8_E5M2)
+        torch.cuda.synchronize()
+        return C, q8, am, cs
+    C0, q0, am0, cs0 = dh(False)
+    C1, q1, am1, cs1 = dh(True)
+    assert torch.equal(q0, q1) and torch.equal(am0, am1) and torch.equal(cs0, cs1) and float(cs0.abs().max()) > 0
+    # refused where no no-output body exists: without the 8-bit copy, on another epilogue, on bf16 operands
+    Cx = torch.empty(M, N, device='cuda', dtype=BF16)
+    for kw in (dict(epilogue=hip.EPI_NO_OUT), dict(epilogue=hip.EPI_BIAS | hip.EPI_QUANT_OUT | hip.EPI_NO_OUT, bias=bias, q8_out=q0, ldq8=N, q8_scale=qs, q8_amax=am0,
+                                                   q8_format=hip.FP8_E4M3)):
+        with pytest.raises(RuntimeError):
+            hip.gemm(hip.GEMM_NT, A.view(torch.uint8), Bw.view(torch.uint8), Cx, M, N, K, K, K, N, fp8_format=hip.FP8_E4M3, scale_a=s, scale_b=s, **kw)
+    Ab, Bb = torch.randn(M, K, generator=g).to(BF16).cuda(), torch.randn(N, K, generator=g).to(BF16).cuda()
+    with pytest.raises(RuntimeError):
+        hip.gemm(hip.GEMM_NT, Ab, Bb, Cx, M, N, K, K, K, N, epilogue=UP | hip.EPI_NO_OUT, bias=bias, aux=auxin, ldaux=N, q8_out=q0, ldq8=N, q8_scale=qs, q8_amax=am0,
+                 q8_format=hip.FP8_E4M3)
+
+    # LayerNorm forward: y == NULL
+    rows, d = 4100, 1024
+    x = torch.randn(rows, d, generator=g).to(BF16).cuda()
+    gamma, beta = torch.randn(d, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+    sc = torch.tensor([0.02], device='cuda')
+
+    def lnf(with_y):
+        y = torch.full((rows, d), 7.0, device='cuda', dtype=BF16)
+        y8 = torch.full((rows, d), 0x7F, dtype=torch.uint8, device='cuda')
+        mean, rstd, am = torch.zeros(rows, device='cuda'), torch.zeros(rows, device='cuda'), torch.zeros(1, device='cuda')
+        check(lib().ecgvit_layernorm_fwd_q8(ptr(x), ptr(gamma), ptr(beta), ptr(y) if with_y else None, ptr(mean), ptr(rstd), rows, d, 1e-5, ptr(y8), ptr(sc), ptr(am),
+                                            stream()), 'ln_fwd_q8')
+        torch.cuda.synchronize()
+        return y, y8, mean, rstd, am
+    a, b = lnf(True), lnf(False)
+    assert all(torch.equal(u, v) for u, v in zip(a[1:], b[1:])) and bool((b[0] == 7.0).all()) and not bool((a[0] == 7.0).all())
+
+    # fused LayerNorm backward: dxm == NULL under dropout
+    dy, dres = (torch.randn(rows, d, generator=g).to(BF16).cuda() for _ in range(2))
+    mean, rstd = x.float().mean(1), 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-5)
+    ws2 = torch.empty(lib().ecgvit_layernorm_bwd_workspace(rows, d), dtype=torch.uint8, device='cuda')
+    sc2 = torch.tensor([1e-4], device='cuda')
+
+    def lnb(with_dxm):
+        dx, dxm = torch.zeros(rows, d, device='cuda', dtype=BF16), torch.full((rows, d), 7.0, device='cuda', dtype=BF16)
+        dg, db, cs, am = torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda'), torch.zeros(d, device='cuda'), torch.zeros(1, device='cuda')
+        g8 = torch.full((rows, d), 0x7F, dtype=torch.uint8, device='cuda')
+        check(lib().ecgvit_layernorm_bwd_fused_q8(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dg), ptr(db), ptr(ws2), rows, d,
+                                                  ptr(dxm) if with_dxm else None, ptr(cs), 0.1, 77, ptr(g8), ptr(sc2), ptr(am), stream()), 'ln_bwd_fused_q8')
+        torch.cuda.synchronize()
+        return dxm, dx, dg, db, cs, g8, am
+    a, b = lnb(True), lnb(False)
+    assert all(torch.equal(u, v) for u, v in zip(a[1:], b[1:])) and bool((b[0] == 7.0).all()) and not bool((a[0] == 7.0).all())
+    # (the non-emitting entry point still needs dxm under dropout)
+    assert lib().ecgvit_layernorm_bwd_fused(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(a[1]), ptr(a[2]), ptr(a[3]), ptr(ws2), rows, d,
+                                            None, ptr(a[4]), 0.1, 77, hip.BF16, stream()) != 0
+
+
+def test_dropping_the_dead_bf16_tensors_changes_no_gradient():
+    """fp8_linear steady state: with the 8-bit copies emitted by their producers, the bf16 xn1 / xn2 / hact / dh / dxm have 8-bit readers only and are
+    not written (engine.fp8_drop_dead_bf16).  Three train steps with and without: losses and every parameter bit-identical."""
+    from oracle import vit_oracle as O
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=512, num_hidden_layers=2, num_attention_heads=8, intermediate_size=1024,
+                          hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    x, y = O.synthetic_batch(20, length=5000, seed=8)      # 20 x 251 = 5020 token rows: above the 8-bit weight-gradient kernel's 4096-row floor
+    x, y = x.cuda(), y.cuda()
+    outs = []
+    for drop in (True, False):
+        torch.manual_seed(6)
+        m = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True).cuda().train()
+        eng = m._engine()
+        assert eng.fp8_drop_dead_bf16
+        eng.fp8_drop_dead_bf16 = drop
+        step = E.HipTrainStep(m, E.get_train_args(dict(train_batch_size=20, num_train_epoch=1, warmup_ratio=0.0), n_train=20 * 20))
+        losses = [float(step.step(x, y)[0]) for _ in range(3)]
+        if drop:   # the tensors really stayed unwritten in the last (steady-state) step: poison them, step, look
+            for L in eng.act['layers']:
+                for k in ('xn1', 'xn2', 'hact'):
+                    L[k].fill_(7.0)
+            eng.act['dh'].fill_(7.0)
+            losses.append(float(step.step(x, y)[0]))
+            for L in eng.act['layers']:
+                for k in ('xn1', 'xn2', 'hact'):
+                    assert bool((L[k] == 7.0).all()), k
+            assert bool((eng.act['dh'] == 7.0).all())
+        else:
+            losses.append(float(step.step(x, y)[0]))
+        outs.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])

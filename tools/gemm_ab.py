@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=5)
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--m', type=int, default=512 * 251)
+    ap.add_argument('--dim', type=int, default=768, help='hidden size (FFN width = 4 x): 512 with --m 64256 = EcgVit-small at 256 records')
     ap.add_argument('--groups', default='0', help='comma list of raster_g values for kernel 2 (0 = built-in choice)')
     ap.add_argument('--check', action='store_true', help='compare kernel 2 with kernel 1 and with an f32 reference on a row sample')
     ap.add_argument('--no-old', action='store_true')
@@ -43,7 +44,7 @@ def main():
     lib = hip.lib()
     tg = lib.ecgvit_tools_gemm
     tg.restype, tg.argtypes = ctypes.c_int, [ctypes.POINTER(hip.GemmDesc), ctypes.c_void_p] + [ctypes.c_int] * 3
-    M, d, f = args.m, 768, 3072
+    M, d, f = args.m, args.dim, 4 * args.dim
     LIN = EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT
     UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT
     DH = EPI_MUL_AUX | EPI_COLSUM
