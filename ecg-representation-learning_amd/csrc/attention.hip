@@ -40,6 +40,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                                                                uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
                                                                float *__restrict__ q8_amax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned int amax_seen = 0u;
+    if constexpr (Q8) amax_seen = amax_peek(q8_amax);   // (consumed behind the last store: common.h, wave_amax_publish)
     const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
     char *Kimg = smem, *Vimg = smem + NK * 128;
     const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
@@ -146,37 +148,65 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
         }
         l += __shfl_xor(l, 32, 64);
         [[maybe_unused]] float qmax = 0.f;
-        if (q < N) {
+        // output: lane (lr, lh) holds columns dt*32 + 8*g4 + 4*lh + {0..3} of query row lr -- 8-B runs interleaved with its partner lane's (lr, lh^1).
+        // One v_permlane32_swap per dword hands each lane of the pair BOTH halves of two g4 groups: 16-B stores of contiguous bytes (4 per wave and
+        // dt instead of 16 of 8 B; the 8-bit copy: ONE 16-B store per dt instead of four of 4 B)
+        {
             const float inv = inv_keep / l;   // inv_keep = 1 without dropout
-            bf16_t *orow = out + ((int64_t)b * N + q) * d + hd * 64;
             [[maybe_unused]] float q8_inv = 0.f;
             if constexpr (Q8) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
+            const int qr = q < N ? q : 0;
+            bf16_t *orow = out + ((int64_t)b * N + qr) * d + hd * 64;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt) {
+                uint32_t D[4][2];
+                [[maybe_unused]] uint32_t W8[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     bf16x4 v;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
-                    *reinterpret_cast<bf16x4 *>(orow + dt * 32 + 8 * g4 + 4 * lh) = v;
+                    const u32x2 vv = __builtin_bit_cast(u32x2, v);
+                    D[g4][0] = vv[0]; D[g4][1] = vv[1];
                     if constexpr (Q8) {
                         float f[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             f[k] = (float)v[k];                       // the value as stored
-                            qmax = fmaxf(qmax, fabsf(f[k]));
+                            qmax = fmaxf(qmax, q < N ? fabsf(f[k]) : 0.f);
                             f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -448.f, 448.f);
                         }
                         int w = 0;
                         w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
                         w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
-                        *reinterpret_cast<uint32_t *>(out8 + ((int64_t)b * N + q) * d + hd * 64 + dt * 32 + 8 * g4 + 4 * lh) = (uint32_t)w;
+                        W8[g4] = (uint32_t)w;
                     }
                 }
-            if (lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
+                // (a, b) -> a' = {lower half: a of lh 0, upper half: b of lh 0}, b' = {lower: a of lh 1, upper: b of lh 1}
+                u32x4 lo, hi;   // g4 = 2*lh and 2*lh + 1: [lh 0: dwords 0, 1 | lh 1: dwords 0, 1]
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(D[0][k], D[2][k], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(D[1][k], D[3][k], false, false);
+                    lo[k] = s0[0]; lo[2 + k] = s0[1];
+                    hi[k] = s1[0]; hi[2 + k] = s1[1];
+                }
+                if (q < N) {
+                    *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh) = lo;
+                    *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh + 8) = hi;
+                }
+                if constexpr (Q8) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(W8[0], W8[2], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(W8[1], W8[3], false, false);
+                    u32x4 w;
+                    w[0] = s0[0]; w[1] = s0[1]; w[2] = s1[0]; w[3] = s1[1];
+                    if (q < N) *reinterpret_cast<u32x4 *>(out8 + ((int64_t)b * N + qr) * d + hd * 64 + dt * 32 + 16 * lh) = w;
+                }
+            }
+            if (q < N && lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
         }
         if constexpr (Q8) {
-            wave_amax_publish(q8_amax, qmax);
+            wave_amax_publish(q8_amax, qmax, amax_seen);
         }
     }
 }
@@ -1013,7 +1043,7 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
                                 uint64_t seed, int dtype, void *stream, void *out8, const float *q8_scale, float *q8_amax) {
     if (dtype != ECGVIT_BF16 || dh != 64 || N < 1 || N > 512 || B < 1 || h < 1) return ECGVIT_EINVAL;
     if ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(out)) % 16) return ECGVIT_EINVAL;
-    if (out8 && (!q8_scale || !q8_amax || reinterpret_cast<uintptr_t>(out8) % 4)) return ECGVIT_EINVAL;
+    if (out8 && (!q8_scale || !q8_amax || reinterpret_cast<uintptr_t>(out8) % 16)) return ECGVIT_EINVAL;   // (16-B stores)
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
@@ -1096,8 +1126,10 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
 #define ATTN_BWD_PRIO 1
 #endif
 #define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER, ATTN_BWD_PRIO>), PERS_ARGS(K0))
-// (the emitting variants run the lockstep schedule: the staggered one has no registers left for the conversions -- 256 VGPRs + spills)
-#define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, false, 1, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
+// (the emitting variants run the staggered schedule as well since round 4's vector diet -- 239-255 VGPRs, no spills -- except the second key
+// window under dropout with all three conversions, which would spill 4 registers: scratch traffic would join the counted vmcnt waits, so that
+// one keeps the lockstep schedule)
+#define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER && !(DR && AC && Q == 3), ATTN_BWD_PRIO, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
     if (g_tools_attn_variant == -2)   // tools build: the four-wave, one-wave-per-SIMD experiment of round 4 (attention_bwd4.hip; measured, not shipped)
         return ecgvit_attention_bwd4_launch(qkv, out, dout, lse, dqkv, B, N, h, scale, th, ik, seed, as_stream(stream), dqkv8, q8_scale, q8_amax);

@@ -71,13 +71,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // launch that sends one per wave and tile (49 k in the attention forward at 512 x 12 x 251, 64 k in an FFN-wide product of EcgVit-large) spent
 // 300-400 us of a 200-500 us kernel on them (profiles/r04_amax_atomics.txt).  The guard reads the slot at device scope (past the CU's L1):
 // a stale value can only be too SMALL, which costs an atomic, never skips one that was needed.  Non-negative floats order as integers.
-__device__ __forceinline__ void wave_amax_publish(float *dst, float v) {
-    v = wave_max(v);
-    if ((threadIdx.x & 63) == 0 && v > 0.f) {
-        unsigned int *slot = reinterpret_cast<unsigned int *>(dst);
-        if (__float_as_uint(v) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(v));
-    }
+// `seen` = amax_peek(dst) taken EARLIER by the caller (at the top of the kernel / of the tile's epilogue): the atomic itself is fire-and-forget,
+// a load consumed on the spot would make the wave wait an L2 round trip (and, behind stores, for every store before it).
+__device__ __forceinline__ unsigned int amax_peek(const float *dst) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned int *>(dst), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void wave_amax_publish(float *dst, float v, unsigned int seen) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(v) > seen) atomicMax(reinterpret_cast<unsigned int *>(dst), __float_as_uint(v));   // (v >= 0: never below a seen 0)
+}
+__device__ __forceinline__ void wave_amax_publish(float *dst, float v) { wave_amax_publish(dst, v, amax_peek(dst)); }
 // sum over a block of NW waves; every thread gets the result. `red` = NW floats of LDS.
 template <int NW> __device__ __forceinline__ float block_sum(float v, float *red) {
     v = wave_sum(v);

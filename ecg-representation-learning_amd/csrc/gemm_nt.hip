@@ -269,6 +269,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll
     for (int k = 0; k < 16; ++k) cs[k] = 0.f;
     float qmax = 0.f;
+    unsigned int amax_seen = 0u;
+    if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) amax_seen = amax_peek(d.q8_amax);   // with the epilogue's up-front loads; consumed behind its last store
     if (FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD)) && e.alpha != 1.f) {
         // light bodies: a REAL wave-uniform branch (the empty asm keeps the compiler from if-converting it): as a select per element it cost every
         // launch with a light body 1.5 VALU instructions per element, alpha == 1 included -- a third of the plain epilogue
@@ -305,6 +307,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int h = 0; h < 2; ++h) { R[i][h] = ld_res(i, h); X[i][h] = ld_aux(i, h); }
+        if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) asm volatile("" : "+v"(amax_seen));   // (waited for here, with the row loads: not behind the pieces)
         issue_next();
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -327,6 +330,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll
             for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(bias[k]));
         }
+        if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) asm volatile("" : "+v"(amax_seen));
         issue_next();
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
@@ -348,7 +352,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         }
     }
     if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // at most one atomic max per wave and tile, only when it raises the slot (common.h: wave_amax_publish)
-        wave_amax_publish(d.q8_amax, qmax);
+        wave_amax_publish(d.q8_amax, qmax, amax_seen);
     }
     if (NT_HAS(ECGVIT_EPI_COLSUM)) {
         // lanes with equal (lane >> 4) hold the same 16 columns: fold the 16 rows, one partial row per (tile row, wm)

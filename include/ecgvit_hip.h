@@ -207,7 +207,7 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
 int ecgvit_attention_fwd(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale,
                          float dropout_p, uint64_t seed, int dtype, void *stream);
 /* fp8 operand path: the same forward that also writes out8 = saturate(out as stored / *q8_scale) in e4m3 (same [B*N, h*dh] layout, one byte
- * per element) and accumulates *q8_amax = max(*q8_amax, max |out|): the 8-bit operand of the out-projection's product, without a quantise pass */
+ * per element, 16-byte aligned) and accumulates *q8_amax = max(*q8_amax, max |out|): the 8-bit operand of the out-projection's product, without a quantise pass */
 int ecgvit_attention_fwd_q8(const void *qkv, void *out, float *lse, int B, int N, int h, int dh, float scale, float dropout_p,
                             uint64_t seed, void *out8, const float *q8_scale, float *q8_amax, void *stream);
 int ecgvit_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv,
