@@ -575,12 +575,16 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     if (PRIO == 2 && !late) __builtin_amdgcn_s_setprio(1);
 #ifdef ECGVIT_TOOLS
     unsigned long long *stamps = g_attn_stamps ? g_attn_stamps + (int64_t)blockIdx.x * 128 : nullptr;
-    // tools build only: per-PHASE stamps of the second item, one record per wave group (lane 0 of waves 0 and 4), behind the 768 block
-    // records of the buffer: [768 + block][group][query block][phase 0..7 = start, issue, A, V, B+W, C, wait, barrier]
+#else
+    unsigned long long *const stamps = nullptr;   // (every stamp below folds away)
+#endif
+#if defined(ECGVIT_TOOLS) && defined(ECGVIT_ATTN_PHASE_STAMPS)
+    // `make tools TOOLS_EXTRA=-DECGVIT_ATTN_PHASE_STAMPS` only (tools/attn_phase_stamps.py): per-PHASE stamps of the second item, one record per wave
+    // group (lane 0 of waves 0 and 4), behind the 768 block records of the buffer: [768 + block][group][query block][phase 0..7 = start, issue, A, V,
+    // B+W, C, wait, barrier].  Not in the default tools build: the per-lane stamp conditions cost the staggered schedule 13 % (570 against 500 us)
     unsigned long long *pstamps = (g_attn_stamps && (lane == 0) && (wave == 0 || wave == 4)) ? g_attn_stamps + (768 + (int64_t)blockIdx.x) * 128 + (wave >> 2) * 64 : nullptr;
 #define PH_STAMP(QB, IDX) do { if (pstamps && item_no == 1 && (QB) < 8) pstamps[(QB) * 8 + (IDX)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-    unsigned long long *const stamps = nullptr;   // (every stamp below folds away)
 #define PH_STAMP(QB, IDX) do { } while (0)
 #endif
     int item_no = 0;

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """diagnostics (tools build): per-PHASE cycle stamps of the persistent attention backward, for lane 0 of wave 0 (leading group) and
-wave 4 (trailing group, half a block late), second item of every workgroup: python tools/attn_phase_stamps.py [p]"""
+wave 4 (trailing group, half a block late), second item of every workgroup: python tools/attn_phase_stamps.py [p]
+Needs the tools library built WITH the phase stamps (they cost the schedule 13 %, so the default tools build leaves them out):
+    touch ecg-representation-learning_amd/csrc/attention.hip && make -C ecg-representation-learning_amd/csrc tools TOOLS_EXTRA=-DECGVIT_ATTN_PHASE_STAMPS"""
 import os, sys, torch, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
