@@ -159,48 +159,49 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             bf16_t *orow = out + ((int64_t)b * N + qr) * d + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                uint32_t D[4][2];
-                [[maybe_unused]] uint32_t W8[4];
+                // column groups (j, j + 2) at a time: (a, b) -> a' = {lower half: a of lh 0, upper half: b of lh 0}, b' = {lower: a of lh 1, upper: b of lh 1},
+                // i.e. lane lh ends up with group 2*lh + j complete: [lh 0: dwords 0, 1 | lh 1: dwords 0, 1] = one 16-B store
+                [[maybe_unused]] u32x4 w8;
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    bf16x4 v;
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t D[2][2];
+                    [[maybe_unused]] uint32_t W8[2];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
-                    const u32x2 vv = __builtin_bit_cast(u32x2, v);
-                    D[g4][0] = vv[0]; D[g4][1] = vv[1];
-                    if constexpr (Q8) {
-                        float f[4];
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g4 = j + 2 * gg;
+                        bf16x4 v;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            f[k] = (float)v[k];                       // the value as stored
-                            qmax = fmaxf(qmax, q < N ? fabsf(f[k]) : 0.f);
-                            f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -448.f, 448.f);
+                        for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
+                        const u32x2 vv = __builtin_bit_cast(u32x2, v);
+                        D[gg][0] = vv[0]; D[gg][1] = vv[1];
+                        if constexpr (Q8) {
+                            float f[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f[k] = (float)v[k];                       // the value as stored
+                                qmax = fmaxf(qmax, q < N ? fabsf(f[k]) : 0.f);
+                                f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -448.f, 448.f);
+                            }
+                            int w = 0;
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
+                            w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
+                            W8[gg] = (uint32_t)w;
                         }
-                        int w = 0;
-                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w, false);
-                        w = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w, true);
-                        W8[g4] = (uint32_t)w;
+                    }
+                    u32x4 st;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(D[0][k], D[1][k], false, false);
+                        st[k] = sw[0]; st[2 + k] = sw[1];
+                    }
+                    if (q < N) *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh + 8 * j) = st;
+                    if constexpr (Q8) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(W8[0], W8[1], false, false);
+                        w8[2 * j] = sw[0]; w8[2 * j + 1] = sw[1];
                     }
                 }
-                // (a, b) -> a' = {lower half: a of lh 0, upper half: b of lh 0}, b' = {lower: a of lh 1, upper: b of lh 1}
-                u32x4 lo, hi;   // g4 = 2*lh and 2*lh + 1: [lh 0: dwords 0, 1 | lh 1: dwords 0, 1]
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(D[0][k], D[2][k], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(D[1][k], D[3][k], false, false);
-                    lo[k] = s0[0]; lo[2 + k] = s0[1];
-                    hi[k] = s1[0]; hi[2 + k] = s1[1];
-                }
-                if (q < N) {
-                    *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh) = lo;
-                    *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh + 8) = hi;
-                }
                 if constexpr (Q8) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(W8[0], W8[2], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(W8[1], W8[3], false, false);
-                    u32x4 w;
-                    w[0] = s0[0]; w[1] = s0[1]; w[2] = s1[0]; w[3] = s1[1];
-                    if (q < N) *reinterpret_cast<u32x4 *>(out8 + ((int64_t)b * N + qr) * d + hd * 64 + dt * 32 + 16 * lh) = w;
+                    if (q < N) *reinterpret_cast<u32x4 *>(out8 + ((int64_t)b * N + qr) * d + hd * 64 + dt * 32 + 16 * lh) = w8;
                 }
             }
             if (q < N && lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
