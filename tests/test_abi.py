@@ -103,3 +103,23 @@ def test_gemm_kernel_route_query_is_host_only():
     assert route(hip.GEMM_NN, hip.F32, hip.F32, 100, 64, 32, 32, 64, 64) == hip.KERNEL_GEMM_F32
     assert route(hip.GEMM_NT, hip.BF16, hip.BF16, M, dm + 4, dm, dm, dm, dm + 4) == hip.KERNEL_NONE                              # N % 8 != 0: rejected
     assert l.ecgvit_gemm_kernel(None) == hip.KERNEL_NONE
+
+
+def test_binding_constants_are_the_headers():
+    """every numeric #define of include/ecgvit_hip.h that the Python binding restates (dtype / layout / epilogue / kernel-family codes, error codes)
+    has the same value there: `ECGVIT_X` <-> `hip.X`"""
+    hip = E.hip
+    text = open(os.path.join(ROOT, 'include', 'ecgvit_hip.h')).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r'^#define ECGVIT_([A-Z0-9_]+)\s+(-?\d+)\b', text, re.M)}
+    assert len(defs) >= 25, defs
+    checked = 0
+    for name, val in defs.items():
+        if hasattr(hip, name):
+            assert getattr(hip, name) == val, (name, val, getattr(hip, name))
+            checked += 1
+    for need in ('F32', 'BF16', 'FP8_E4M3', 'BF8_E5M2', 'GEMM_NT', 'GEMM_NN', 'GEMM_TN', 'EPI_BIAS', 'EPI_GELU', 'EPI_GELU_BWD', 'EPI_RESIDUAL', 'EPI_ACCUM',
+                 'EPI_DROPOUT', 'EPI_COLSUM', 'EPI_GELU_GRAD_AUX', 'EPI_MUL_AUX', 'EPI_QUANT_OUT', 'EPI_NO_OUT', 'KERNEL_NONE', 'KERNEL_GEMM_F32',
+                 'KERNEL_GEMM_BF16', 'KERNEL_GEMM_NT', 'KERNEL_GEMM_WGRAD'):
+        assert need in defs and hasattr(hip, need), need
+    assert checked >= 23
+    assert {1: 'EINVAL', 2: 'ELAUNCH'} == {defs['EINVAL']: 'EINVAL', defs['ELAUNCH']: 'ELAUNCH'} and set(hip._ERR) == {1, 2}
