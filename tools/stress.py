@@ -15,7 +15,7 @@ bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'ntlin', 'nt8', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
+    kind = rng.choice(['nt', 'nt', 'ntlin', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -60,6 +60,33 @@ while time.time() < t_end:
                      tiles_per_workgroup=rng.choice([0, 0, 2]))
             if not torch.equal(C, want):
                 bad += 1; print('NT8 MISMATCH', M, N, K, afmt, int((C != want).sum()), flush=True)
+        n_nt += 1
+    elif kind == 'nt8emit':  # the FFN-wide emitting epilogues of the 8-bit kernel on random shapes: writing form vs no-output form (ABI 5), bit for bit
+        M = rng.choice([2048, 4133, 20000, 66000]) + rng.randrange(0, 256)
+        N = rng.choice([256, 520, 1024, 3072, 4096])
+        K = 128 * rng.randrange(3, 17)
+        up = rng.random() < 0.5
+        afmt, adt = (hip.FP8_E4M3, torch.float8_e4m3fn) if up else (hip.BF8_E5M2, torch.float8_e5m2)
+        A = (torch.randn(M, K, device='cuda') * 2).to(adt); B = (torch.randn(N, K, device='cuda') * 0.2).to(torch.float8_e4m3fn)
+        s1 = torch.tensor([0.5], device='cuda'); qs = torch.tensor([0.02 if up else 1e-3], device='cuda')
+        bias = torch.randn(N, device='cuda'); auxin = (torch.rand(M, N, device='cuda') * 1.2).to(bf)
+        ws = torch.empty(max(lib().ecgvit_colsum_workspace(M, N), 8 * ((M + 255) // 256) * N), dtype=torch.uint8, device='cuda')
+        drop = up and rng.random() < 0.5
+        res = []
+        for no_out in (False, True, True):
+            C = torch.full((M, N), 7.0, device='cuda', dtype=bf); q8 = torch.full((M, N), 0x7F, dtype=torch.uint8, device='cuda')
+            am, cs = torch.zeros(1, device='cuda'), torch.zeros(N, device='cuda')
+            aux = torch.zeros(M, N, device='cuda', dtype=bf) if up else auxin
+            epi = (hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX | (hip.EPI_DROPOUT if drop else 0)) if up else (hip.EPI_MUL_AUX | hip.EPI_COLSUM)
+            hip.gemm(hip.GEMM_NT, A.view(torch.uint8), B.view(torch.uint8), None if no_out else C, M, N, K, K, K, N, fp8_format=afmt, scale_a=s1, scale_b=s1,
+                     epilogue=epi | hip.EPI_QUANT_OUT | (hip.EPI_NO_OUT if no_out else 0), bias=bias if up else None, aux=aux, ldaux=N, dropout_p=0.1 if drop else 0.0, seed=5,
+                     workspace=ws, colsum_out=None if up else cs, q8_out=q8, ldq8=N, q8_scale=qs, q8_amax=am, q8_format=hip.FP8_E4M3 if up else hip.BF8_E5M2,
+                     tiles_per_workgroup=rng.choice([0, 0, 2]))
+            res.append((q8, am, cs, aux.clone() if up else None, C))
+        ok = all(torch.equal(res[0][i], r[i]) for r in res[1:] for i in (0, 1, 2)) and (not up or all(torch.equal(res[0][3], r[3]) for r in res[1:]))
+        ok = ok and bool((res[1][4] == 7.0).all()) and float(res[0][1]) == float(res[0][4].float().abs().max())
+        if not ok:
+            bad += 1; print('NT8-EMIT MISMATCH', M, N, K, up, drop, flush=True)
         n_nt += 1
     elif kind == 'tn':
         M = 256 * rng.randrange(1, 13); N = 256 * rng.randrange(1, 13)
