@@ -953,6 +953,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
 
 }  // namespace
 
+static int nt_default_group(int tiles_n) { return tiles_n <= 8 ? tiles_n : 6; }   // n-tiles per column group of the built-in tile walk (ecgvit_gemm_nt_launch)
+
 bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     const bool f8 = d->dtype == ECGVIT_FP8_E4M3 || d->dtype == ECGVIT_BF8_E5M2;
     if (d->layout != ECGVIT_GEMM_NT || !(d->dtype == ECGVIT_BF16 || f8)) return false;
@@ -1000,7 +1002,8 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     // Built-in tile walk: column groups of 6 n-tiles (m-major inside a group).  Measured inside the train step against the plain
     // n-fastest order (tools/pmc_step_raster.sh, tools/ab_bench.sh ECGVIT_NT_G): the same step time (+-0.02 %) with 13 % fewer bytes
     // fetched from beyond L2 per launch (1.08 -> 0.94 GB); groups of 3 fetch 0.97 GB at -0.1 %, groups of 4 cost 0.6 % of the step.
-    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);
+    // Up to 8 n-tiles (N <= 2048: the FFN-wide products of EcgVit-small) stay ONE group -- a 6 + 2 split costs that step 0.9 % (round 4).
+    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : nt_default_group(tiles_n);
     const EpiParams e = make_epi(d);
     // persistent (one workgroup per CU, static shares) unless the caller asks for dispatcher-balanced chunks of ~k tiles
     const int tpw = d->tiles_per_workgroup;
@@ -1112,7 +1115,7 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
     // (the FFN-down input gradient's body -- x aux, column sums -- measured 1,044 us on this body against 696: 288 B of spills, one wave's VALU)
     if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT)) return ECGVIT_EINVAL;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
-    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : std::min(6, tiles_n);
+    const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : nt_default_group(tiles_n);
     const int tpw = d->tiles_per_workgroup;   // > 0: dispatcher-balanced chunks of ~tpw tiles, as in ecgvit_gemm_nt_launch
     const dim3 grid((unsigned)(tpw > 0 ? std::max(std::min(ntile, 256), (ntile + tpw - 1) / tpw) : std::min(ntile, 256))), block(256);
 #define NT4W_GO(FL, CAUX, ST, AB) hipLaunchKernelGGL((gemm_nt_kernel_4w<bf16_t, FL, CAUX, ST>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, AB)
