@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The four weight-gradient products of one EcgVit-base layer (dW = dY^T . X, f32 output, K = 512*251 token rows): gemm_wgrad_kernel_4w
 (what ships) against the eight-wave gemm_wgrad_kernel (tools build: ecgvit_tools_wgrad_body) and torch.matmul (hipBLASLt, bf16 operands, f32 result via a bf16 output upcast is NOT equivalent -- the library is timed with bf16
-output as a lower bound of its work), interleaved in one process.  usage: python tools/wgrad_ab.py [rounds]"""
+output as a lower bound of its work), interleaved in one process.  usage: python tools/wgrad_ab.py [rounds] [records tokens hidden]   (e.g. 5 256 251 512 = the EcgVit-small shapes)"""
 import os
 import sys
 
@@ -17,7 +17,8 @@ from ecg_representation_learning_amd.hip import GEMM_TN  # noqa: E402
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    M, d, f, bf, dev = 512 * 251, 768, 3072, torch.bfloat16, 'cuda'
+    recs, toks, d = (int(a) for a in sys.argv[2:5]) if len(sys.argv) > 4 else (512, 251, 768)
+    M, f, bf, dev = recs * toks, 4 * d, torch.bfloat16, 'cuda'
     shapes = [('qkv', 3 * d, d), ('out', d, d), ('ffn_up', f, d), ('ffn_down', d, f)]
     ws = torch.empty(hip.gemm_workspace_bytes(GEMM_TN, bf, f, f, M) + (64 << 20), dtype=torch.uint8, device=dev)
     data = {}
