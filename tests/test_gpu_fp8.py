@@ -373,6 +373,8 @@ def test_attention_kernels_emit_their_8bit_copies(N, p):
     assert float(same.float().mean()) > 0.9999, float(same.float().mean())
     # short sequences run the one-item kernel, which does not emit: the entry point says so instead of leaving the copy unwritten
     assert lib().ecgvit_attention_bwd_q8(ptr(qkv), ptr(out), ptr(do), ptr(lse), ptr(dq2), 2, 100, h, dh, 0.125, p, 7, ptr(dq8), ptr(s_dq), ptr(amax), stream()) == 1
+    # the 8-bit copy of the forward leaves in 16-byte stores: a copy that is not 16-byte aligned is refused, not written misaligned
+    assert lib().ecgvit_attention_fwd_q8(ptr(qkv), ptr(out2), ptr(lse2), B, N, h, dh, 0.125, p, 7, out8.data_ptr() + 4, ptr(s_out), ptr(amax), stream()) == 1
 
 
 def test_no_output_forms_emit_exactly_what_the_writing_forms_emit():
