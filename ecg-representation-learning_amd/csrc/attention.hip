@@ -109,25 +109,31 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
-            const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0
-            m = mn;
-            const float mc = mn * c;
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));   // one fma per score (the kernel is VALU-bound); argument <= 0 up to rounding
-                s[r] = p;
-                ls += p;
-            }
-            l = l * alpha + ls;                             // per-half partial sums; halves are combined after the loop
-            if (!__all(alpha == 1.0f)) {  // wave-uniform: most tiles after the first few leave every query's max untouched
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // (NOT v_permlane32_swap(mx, mx): with one value as both operands hipcc treats the two results as equal)
+            // LAZY running maximum: the reference m of a query moves only when a tile's maximum exceeds it by more than 2^8 in the exponent, so a tile's
+            // probabilities are at most 256 relative to it (bf16 / f32 keep the same relative precision there; the sums stay far inside f32) and the common
+            // tile has no exponential of alpha and no rescale of the 32 output accumulators (16 packed multiplies that cost double beside the MFMAs: ~15 % of
+            // a tile's vector work).  The exact maximum is not needed: out = sum(p v) / sum(p) and LSE = m scale + log(sum p) hold for any reference m.
+            // Wave-uniform branch; always taken on the first tile (m = -inf), after that only when attention is peaked enough to jump by 2^8.
+            if (__any((mx - m) * c > 8.0f)) {
+                const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
+                const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0; lanes that do not move: 1
+                m = mn;
+                l *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             }
+            const float mc = m * c;
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));   // one fma per score (the kernel is VALU-bound); argument <= 8
+                s[r] = p;
+                ls += p;
+            }
+            l += ls;                                        // per-half partial sums; halves are combined after the loop
             if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout); the
                 // 1/(1-p) rescale is folded into the final normalisation.  My 16 keys are 4 quads: kt*32 + 8g + 4*lh + {0..3}
                 const uint32_t hb = (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix;

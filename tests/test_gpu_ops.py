@@ -373,6 +373,45 @@ def test_attention_bf16_fwd_bwd(N):
         assert rel_err(got, ref) < 2e-2, (nm, rel_err(got, ref))
 
 
+@pytest.mark.parametrize('N', [251, 501])
+@pytest.mark.parametrize('shape', ['rising', 'falling', 'spike'])
+def test_attention_fwd_lazy_running_maximum(N, shape):
+    """the forward keeps a LAZY running maximum: a query's reference moves only when a key tile exceeds it by more than 2^8 in the exponent.  Peaked score
+    profiles take every path of that rule -- keys whose scores RISE tile after tile (the reference is moved again and again), FALL (it never moves after the
+    first tile and later tiles underflow towards zero), and one SPIKE key deep in the row (one move of hundreds of exponent units) -- against the fp64 softmax;
+    the backward, which rebuilds the probabilities from the stored LSE, against autograd"""
+    g = torch.Generator().manual_seed(N)
+    B, h, dh = 2, 3, 64
+    d = h * dh
+    scale = dh ** -0.5
+    x = torch.randn(B, N, 3, h, dh, generator=g)
+    ramp = torch.linspace(0.2, 6.0, N).view(1, N, 1, 1)
+    if shape == 'rising':
+        x[:, :, 1] *= ramp            # |k| grows with the key index: the row maximum keeps moving up
+    elif shape == 'falling':
+        x[:, :, 1] *= ramp.flip(1)
+    else:
+        x[:, N - 40, 1] *= 25.0       # one key with scores in the hundreds, in the last tiles
+    qkv = x.reshape(B * N, 3 * d).to(BF16)
+    qd = dev(qkv)
+    out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
+    lse = torch.zeros(B * h * N, device='cuda')
+    check(lib().ecgvit_attention_fwd(ptr(qd), ptr(out), ptr(lse), B, N, h, dh, scale, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
+    qr = qkv.double().requires_grad_(True)
+    o_ref, lse_ref, _ = _attn_ref(qr, B, N, h, dh, scale)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert rel_err(out, o_ref) < 1e-2, rel_err(out, o_ref)
+    assert max_err(lse.view(B, h, N), lse_ref) < 2e-3 * max(1.0, float(lse_ref.abs().max()) / 50)     # f32 LSE: absolute error grows with its magnitude
+    do = torch.randn(B * N, d, generator=g).to(BF16)
+    o_ref.backward(do.double())
+    dqkv = torch.full((B * N, 3 * d), float('nan'), device='cuda', dtype=BF16)
+    check(lib().ecgvit_attention_bwd(ptr(qd), ptr(out), ptr(dev(do)), ptr(lse), ptr(dqkv), B, N, h, dh, scale, 0.0, 0, hip.BF16, stream()), 'attn_bwd')
+    assert torch.isfinite(dqkv.float()).all()
+    for i, nm in enumerate('qkv'):
+        got, ref = dqkv[:, i * d:(i + 1) * d], qr.grad[:, i * d:(i + 1) * d]
+        assert rel_err(got, ref) < 3e-2, (nm, rel_err(got, ref))
+
+
 @pytest.mark.parametrize('N', [501, 257, 300, 512, 449])
 def test_attention_bf16_long_forward_501(N):
     """forward covers N <= 512 (seq = 500 patches + CLS, the 'large' long-record geometry).  Above 256 tokens a workgroup owns one 256-query half
