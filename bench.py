@@ -96,7 +96,15 @@ class GemmProbe:
                 e1.record()
                 probe.events.append((e0, e1))
                 probe.flops += 2.0 * M * N * K
-                probe.bytes += (1.0 if f8 else 2.0) * (M * K + N * K) + (1.0 if C is None else 2.0) * M * N
+                # algorithmic bytes = every tensor the launch must read or write ONCE: both operands, the output when it is written, and what
+                # the epilogue streams -- residual rows, the saved GELU' x mask tensor (written by the FFN-up forward, read by the FFN-down
+                # input gradient), the 8-bit copy of the output (round 5; before, only operands + C were counted: 0.793 GB per launch at base
+                # where this count gives 0.86)
+                epi = k.get('epilogue', 0)
+                nb = (1.0 if f8 else 2.0) * (M * K + N * K) + (0.0 if C is None else 2.0) * M * N
+                nb += 2.0 * M * N * (bool(epi & probe.hip.EPI_RESIDUAL) + bool(epi & (probe.hip.EPI_GELU_GRAD_AUX | probe.hip.EPI_MUL_AUX | probe.hip.EPI_GELU_BWD | probe.hip.EPI_GELU)))
+                nb += 1.0 * M * N * bool(epi & probe.hip.EPI_QUANT_OUT)
+                probe.bytes += nb
                 probe.n8 += 1 if f8 else 0
         self.hip.gemm = gemm
         import ecg_representation_learning_amd.engine as eng

@@ -19,10 +19,6 @@
 #include "attn_common.h"
 #include <cstdlib>
 
-// attention_bwd4.hip (tools library only: the four-wave experiment of round 4)
-int ecgvit_attention_bwd4_launch(const void *qkv, const void *out, const void *dout, const float *lse, void *dqkv, int B, int N, int h, float scale,
-                                 uint32_t th, float ik, uint64_t seed, hipStream_t stream, void *dqkv8, const float *q8_scale, float *q8_amax);
-
 namespace {
 
 // =====================================================================================================
@@ -1142,8 +1138,6 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
 // one keeps the lockstep schedule)
 #define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER && !(DR && AC && Q == 3), ATTN_BWD_PRIO, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
-    if (g_tools_attn_variant == -2)   // tools build: the four-wave, one-wave-per-SIMD experiment of round 4 (attention_bwd4.hip; measured, not shipped)
-        return ecgvit_attention_bwd4_launch(qkv, out, dout, lse, dqkv, B, N, h, scale, th, ik, seed, as_stream(stream), dqkv8, q8_scale, q8_amax);
     if (g_tools_attn_variant >= 0 && th && N <= 256 && !dqkv8) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)
         switch (g_tools_attn_variant) {
             case 0: hipLaunchKernelGGL((attn_bwd_pers_kernel<true, false, false, 1>), PERS_ARGS(0)); break;   // lockstep

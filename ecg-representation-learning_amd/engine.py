@@ -25,6 +25,13 @@ def _align(n, a=8):
     return (n + a - 1) // a * a
 
 
+def _numel(shape):
+    n = 1
+    for v in shape:
+        n *= v
+    return n
+
+
 class ParamLayout:
     """name -> (offset, shape) inside one flat f32 buffer; every tensor starts on a 64-B boundary so the same
     offsets address the bf16 shadow on 32-B and the 8-bit shadows on 16-B boundaries (vector loads everywhere)."""
@@ -115,6 +122,7 @@ class VitEngine:
         self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
         self.B = None
         self._alloc_key = None
+        self._pool, self._pool_group, self._pool_B = None, None, 0
         self.T = self.N
         self.act = None
         self.P32 = self.G32 = self.W = None
@@ -218,12 +226,22 @@ class VitEngine:
         """the bf16 copies with 8-bit readers only may be left unwritten in a pass over M token rows (see `fp8_drop_dead_bf16`)"""
         return self.fp8 and self.fp8_drop_dead_bf16 and M >= 4096
 
+    def _bf16_reader(self, M, what):
+        """called by every bf16 fallback of a block product: when `_only8(M)` holds, the producers have left xn1 / xn2 / hact / dh / dxm
+        UNWRITTEN on the promise that every reader takes its 8-bit kernel -- a reader that falls back to bf16 would consume stale
+        buffers from an earlier step and return wrong gradients without any error.  The promise is written out in several places
+        (`_only8`, `_wgrad`, `_dgrad`, the library's applicability checks); if they ever drift apart, fail here"""
+        if self._only8(M):
+            raise RuntimeError(f'fp8_linear: {what} fell back to its bf16 kernel over {M} rows while the bf16 operand copies are not '
+                               f'written (fp8_drop_dead_bf16); the 8-bit applicability conditions have drifted apart')
+
     def _linear(self, site, A, name, C, M, N, K, a8=None, emit_site=None, emit_to=None, prequant=False, emit_only8=False, **kw):
         """C = epilogue(A . W^T) for block Linear `name`: bf16 operands, or (fp8_linear) A quantised to e4m3 against the e4m3 shadow.
         a8: this layer's persistent e4m3 copy of A (written here, or already by A's producer when `prequant`; the weight-gradient
         product of the backward pass reads it again); emit_site / emit_to: the site that consumes C next and its persistent copy
         (then written by this epilogue).  Returns True when the 8-bit copy of C was emitted."""
         if not self.fp8 or M < 2048:    # the 8-bit kernel covers the large products only: small batches run bf16
+            self._bf16_reader(M, 'Linear ' + name)
             self._gemm(GEMM_NT, A, self.W[name], C, M, N, K, K, K, N, **kw)
             return False
         if prequant:   # the producer (LayerNorm forward, a GEMM epilogue) already wrote A's 8-bit copy into a8
@@ -264,6 +282,8 @@ class VitEngine:
         operand scratch, True: a GEMM epilogue into q8b).  None when the 8-bit path does not apply."""
         if prequant:
             return self.act['q8' if prequant == 'q8' else 'q8b'][:count], self.f8_scale[site:site + 1]
+        # (not prequant: the producer did not emit the copy and therefore DID write its bf16 output -- `_emit8` / the q8 LayerNorm branch arm
+        # "no bf16 output" and "8-bit copy emitted" together, and report it through the return value that became `prequant`)
         return self._quant(site, dY, count)
 
     def _dgrad(self, dY, name, dX, M, kin, nout, site=None, emit_site=None, pre=None, emit_only8=False, **kw):
@@ -277,6 +297,8 @@ class VitEngine:
             self._gemm(GEMM_NT, q, self.WT8[name], None if kw.get('epilogue', 0) & hip.EPI_NO_OUT else dX, M, kin, nout, nout, nout, kin,
                        fp8_format=hip.BF8_E5M2, scale_a=sc, scale_b=self.w8_scale[mi:mi + 1], **kw)
             return emitted
+        if self.fp8:
+            self._bf16_reader(M, 'input gradient of ' + name)
         wt = self.WT.get(name)
         if wt is not None and M >= 2048:
             self._gemm(GEMM_NT, dY, wt, dX, M, kin, nout, nout, nout, kin, **kw)
@@ -284,53 +306,78 @@ class VitEngine:
             self._gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
 
     def _alloc(self, B, masked=False, m=0):
+        """Activation slabs for a pass over B records.  Every slab's leading dimension is proportional to B, so ONE pool sized for the
+        largest batch seen serves every smaller one through prefix views: a loop that alternates train (B = 512) and eval (B = 64)
+        batches, or ends an epoch on a short batch, re-slices instead of freeing and re-requesting ~40 GB (base) from the allocator on
+        each switch.  The pool is re-made only when a LARGER batch arrives or the objective changes (supervised <-> masked, or another
+        mask count: a different token geometry)."""
         key = (B, masked, m)
         if self._alloc_key == key and self.act is not None:
             return
         self._alloc_key = key
         self.T = self.n if masked else self.N   # tokens per record: no CLS row in the masked-pretrain trunk
-        dev, T = self.device, self.dtype
-        M, Mp = B * self.T, B * self.n
-        d, f, h, N = self.d, self.f, self.h, self.T
-        e = lambda *s, dt=T: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
-        a = dict(patches=e(Mp, self.CP), tok=e(Mp, d), x0=e(M, d))
-        L = []
-        for _ in range(self.Ly):
-            l = dict(mean1=e(M, dt=torch.float32), rstd1=e(M, dt=torch.float32), xn1=e(M, d), qkv=e(M, 3 * d),
-                     attn=e(M, d), x1=e(M, d), mean2=e(M, dt=torch.float32), rstd2=e(M, dt=torch.float32),
-                     xn2=e(M, d), hpre=e(M, f), hact=e(M, f), x2=e(M, d))
-            if T == torch.float32:
-                l['probs'] = e(B * h * N * N)
+        spec = self._act_spec(B, masked, m)
+        group = (masked, m)
+        pool = self._pool if self._pool_group == group else None
+        if pool is None or any(k not in pool or pool[k].dtype != dt or pool[k].numel() < _numel(sh) for k, (sh, dt) in spec.items()):
+            # grow-only inside a group (a workspace size need not be monotone in B): no batch-size sequence makes the pool thrash
+            have = {k: v.numel() for k, v in pool.items()} if pool is not None else {}
+            self.act = self._pool = pool = None   # (drop the old slabs before asking for the new ones)
+            self._pool_group, self._pool_B = group, max(B, self._pool_B if have else 0)
+            self._pool = pool = {k: torch.empty(max(_numel(sh), have.get(k, 0)), device=self.device, dtype=dt) for k, (sh, dt) in spec.items()}
+        a, layers = {}, [dict() for _ in range(self.Ly)]
+        for k, (sh, dt) in spec.items():
+            v = pool[k][:_numel(sh)].view(sh)
+            if k[0] == 'L' and '.' in k:
+                i, kk = k[1:].split('.', 1)
+                layers[int(i)][kk] = v
             else:
-                l['lse'] = e(B * h * N, dt=torch.float32)
+                a[k] = v
+        a['layers'] = layers
+        self.act, self.B = a, B
+
+    def _act_spec(self, B, masked, m):
+        """name -> (shape, dtype) of every activation / scratch slab of a pass over B records (layer slabs as 'L{i}.{name}')"""
+        T = self.dtype
+        f32, u8 = torch.float32, torch.uint8
+        N = self.n if masked else self.N
+        M, Mp = B * N, B * self.n
+        d, f, h = self.d, self.f, self.h
+        sp = OrderedDict()
+        sp.update(patches=((Mp, self.CP), T), tok=((Mp, d), T), x0=((M, d), T))
+        for i in range(self.Ly):
+            l = dict(mean1=((M,), f32), rstd1=((M,), f32), xn1=((M, d), T), qkv=((M, 3 * d), T), attn=((M, d), T), x1=((M, d), T),
+                     mean2=((M,), f32), rstd2=((M,), f32), xn2=((M, d), T), hpre=((M, f), T), hact=((M, f), T), x2=((M, d), T))
+            if T == torch.float32:
+                l['probs'] = ((B * h * N * N,), T)
+            else:
+                l['lse'] = ((B * h * N,), f32)
             if self.fp8 and M >= 2048:
                 # e4m3 copies of the four Linear inputs, kept for the backward pass: the 8-bit weight-gradient products read them again
                 # (one byte per element next to the two of the bf16 tensors: +0.9 GB per layer for large at 256 x 501 tokens)
-                l.update(xn1_8=e(M * d, dt=torch.uint8), attn_8=e(M * d, dt=torch.uint8), xn2_8=e(M * d, dt=torch.uint8), hact_8=e(M * f, dt=torch.uint8))
-            L.append(l)
-        a['layers'] = L
-        a.update(logits=e(B, self.K, dt=torch.float32), xhat=e(B, d, dt=torch.float32), hrstd=e(B, dt=torch.float32),
-                 loss_elem=e(B, self.K, dt=torch.float32), loss_mean=e(1, dt=torch.float32),
-                 dlogits=e(B, self.K, dt=torch.float32))
+                l.update(xn1_8=((M * d,), u8), attn_8=((M * d,), u8), xn2_8=((M * d,), u8), hact_8=((M * f,), u8))
+            for k, v in l.items():
+                sp[f'L{i}.{k}'] = v
+        sp.update(logits=((B, self.K), f32), xhat=((B, d), f32), hrstd=((B,), f32), loss_elem=((B, self.K), f32), loss_mean=((1,), f32),
+                  dlogits=((B, self.K), f32))
         # backward scratch (shared by all layers)
-        a.update(dxa=e(M, d), dxb=e(M, d), dxn=e(M, d), dqkv=e(M, 3 * d), dattn=e(M, d), dh=e(M, f), dtok=e(Mp, d),
-                 dxm=e(M, d))
+        sp.update(dxa=((M, d), T), dxb=((M, d), T), dxn=((M, d), T), dqkv=((M, 3 * d), T), dattn=((M, d), T), dh=((M, f), T),
+                  dtok=((Mp, d), T), dxm=((M, d), T))
         if T == torch.float32:
-            a.update(pd=e(B * h * N * N), dp=e(B * h * N * N))
+            sp.update(pd=((B * h * N * N,), T), dp=((B * h * N * N,), T))
         l = lib()
         ws = max(l.ecgvit_layernorm_bwd_workspace(M, d), l.ecgvit_colsum_workspace(M, max(f, 3 * d)), 8 * ((M + 255) // 256) * f, 4096)
         if T == torch.bfloat16:
             for (mm, nn) in ((d, f), (f, d), (d, d), (3 * d, d), (d, self.CP)):
                 ws = max(ws, hip.gemm_workspace_bytes(GEMM_TN, T, mm, nn, M))
         if masked:
-            a.update(flag=torch.empty(Mp, device=dev, dtype=torch.uint8), rows=e(B * m, d), pred=e(B * m, self.CP),
-                     target=e(B * m, self.CP), dpred=e(B * m, self.CP), drows=e(B * m, d), dmasked=e(Mp, d),
-                     mloss=e(1, dt=torch.float32), l1part=e(1024, dt=torch.float32))
-        a['ws'] = torch.empty(ws, device=dev, dtype=torch.uint8)
+            sp.update(flag=((Mp,), u8), rows=((B * m, d), T), pred=((B * m, self.CP), T), target=((B * m, self.CP), T),
+                      dpred=((B * m, self.CP), T), drows=((B * m, d), T), dmasked=((Mp, d), T), mloss=((1,), f32), l1part=((1024,), f32))
+        sp['ws'] = ((ws,), u8)
         if self.fp8:
-            a['q8'] = torch.empty(M * max(f, 3 * d), device=dev, dtype=torch.uint8)   # one quantised operand at a time
-            a['q8b'] = torch.empty(M * f, device=dev, dtype=torch.uint8)               # 8-bit copies written by a producing epilogue
-        self.act, self.B = a, B
+            sp['q8'] = ((M * max(f, 3 * d),), u8)   # one quantised operand at a time
+            sp['q8b'] = ((M * f,), u8)              # 8-bit copies written by a producing epilogue
+        return sp
 
     # ---------------------------------------------------------------- small launch helpers
     def _ln_fwd(self, x, g, b, y, mean, rstd, rows, q8_site=None, y8=None):
@@ -385,6 +432,8 @@ class VitEngine:
             self._gemm(GEMM_TN, q, x8, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'], fp8_format=hip.BF8_E5M2,
                        scale_a=sc, scale_b=self.f8_scale[xsite:xsite + 1])
             return
+        if self.fp8 and name.startswith('vit.transformer.'):
+            self._bf16_reader(rows, 'weight gradient of ' + name)
         self._gemm(GEMM_TN, dY, X, self.G32[name], Mout, Nin, rows, Mout, Nin, Nin, workspace=self.act['ws'])
 
     # ---------------------------------------------------------------- forward
@@ -466,7 +515,11 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, labels=labels, weight=weight, masked=False, training=training)
-        if self.fp8 and training:   # (an eval forward keeps the scales it finds: a backward pass that is still pending reads them at launch time)
+        if self.fp8:
+            # EVERY forward, eval included, starts from the scales of the pass before it (delayed scaling with a history of one pass): an
+            # inference-only model otherwise keeps its first batch's scales forever and clamps larger activations silently.  No backward can be
+            # waiting for the old scales: a later forward overwrites the activations that backward reads (one live graph per model -- the
+            # autograd node raises on a stale backward)
             self.fp8_begin_step()
         pre = 'vit.'
         self._patch_embed(x, B)
@@ -500,7 +553,7 @@ class VitEngine:
         ph = self.p_hidden if training else 0.0
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m, training=training)
-        if self.fp8 and training:
+        if self.fp8:
             self.fp8_begin_step()
         self._patch_embed(x, B)
         check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),
@@ -537,15 +590,18 @@ class VitEngine:
         if gscalar is not None:
             check(l.ecgvit_l1_loss_fwd_bwd(ptr(a['pred']), ptr(a['target']), ptr(a['mloss']), ptr(a['dpred']), ptr(gscalar), ptr(a['l1part']), B * m,
                                            self.CP, self.CP, T, st), 'l1_loss')
+        # the classification head does not take part: its gradients are zero for this objective -- known at once, so its bucket is
+        # released FIRST and its exchange overlaps the whole backward pass (buckets complete in the order head, layers L-1..0, embed,
+        # pretrain, as in the supervised pass)
+        for k in ('vit.mlp_head.0.weight', 'vit.mlp_head.0.bias', 'vit.mlp_head.1.weight', 'vit.mlp_head.1.bias', 'vit.cls_token'):
+            G[k].zero_()
+        self._ready('head')
         self._colsum(a['dpred'], self.CP, G['pretrain.to_pixels.bias'], B * m, self.CP)
         self._wgrad(a['dpred'], a['rows'], 'pretrain.to_pixels.weight', self.CP, d, B * m)
         self._gemm(GEMM_NN, a['dpred'], W['pretrain.to_pixels.weight'], a['drows'], B * m, d, self.CP, self.CP, d, d)
         dX = a['dxa']
         dX.zero_()
         check(l.ecgvit_scatter_rows(ptr(a['drows']), ptr(idx), ptr(dX), B, n, m, d, d, d, T, st), 'scatter_rows')
-        # the classification head does not take part: its gradients are zero for this objective
-        for k in ('vit.mlp_head.0.weight', 'vit.mlp_head.0.bias', 'vit.mlp_head.1.weight', 'vit.mlp_head.1.bias', 'vit.cls_token'):
-            G[k].zero_()
         dX = self._trunk_bwd(dX, a['dxb'])
         if pe > 0:
             self._drop_apply(dX, dX, B * n * d, pe, seed + 1)
@@ -554,7 +610,6 @@ class VitEngine:
         self._colsum(a['dmasked'], d, G['pretrain.mask_token'], B * n, d)
         self._colsum(a['dtok'], d, G['vit.to_patch_embedding.1.bias'], B * n, d)
         self._wgrad(a['dtok'], a['patches'], 'vit.to_patch_embedding.1.weight', d, self.CP, B * n)
-        self._ready('head')
         self._ready('embed')
         self._ready('pretrain')
 

@@ -115,10 +115,10 @@ class DeviceFeeder:
     def _gather(self, rows, x_buf, y_buf):
         b = len(rows)
         src = self.idxs[rows]
-        order = np.argsort(src, kind='stable')                   # HDF5 / memmap fancy indexing wants increasing indices
-        tmp = np.asarray(self.rec[src[order]] if hasattr(self.rec, 'id') else self.rec[src[order]])
-        inv = np.empty_like(order)
-        inv[order] = np.arange(b)
+        # HDF5 fancy indexing wants STRICTLY increasing indices (and a memmap reads best that way): read each distinct record once, in
+        # increasing order, and scatter -- with pad=True the epoch's order wraps around, so a batch may name a record twice
+        uniq, inv = np.unique(src, return_inverse=True)
+        tmp = np.asarray(self.rec[uniq])
         x_buf[:b].numpy()[...] = tmp[inv]                        # float64 -> float32 happens in this assignment
         y_buf[:b].numpy()[...] = self.labels[rows]
         return b

@@ -9,7 +9,7 @@ import textwrap
 from conftest import ROOT
 
 
-def _run_launcher(tmp_path, child_body, n=3):
+def _run_launcher(tmp_path, child_body, n=3, extra=()):
     # a copy of bench.py whose main() is replaced by the stand-in once WORLD_SIZE is set (= in the children)
     src = open(os.path.join(ROOT, 'bench.py')).read()
     marker = "    rank = int(os.environ.get('RANK', 0))\n"
@@ -19,7 +19,7 @@ def _run_launcher(tmp_path, child_body, n=3):
     with open(path, 'w') as f:
         f.write(src.replace("ROOT = os.path.dirname(os.path.abspath(__file__))", f"ROOT = {ROOT!r}"))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
-    return subprocess.run([sys.executable, path, '--gpus', str(n), '--steps', '2'], env=env, capture_output=True, text=True, timeout=300)
+    return subprocess.run([sys.executable, path, '--gpus', str(n), '--steps', '2', *extra], env=env, capture_output=True, text=True, timeout=300)
 
 
 def test_launcher_starts_n_ranks_and_relays_rank0(tmp_path):
@@ -34,6 +34,17 @@ def test_launcher_starts_n_ranks_and_relays_rank0(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert lines == ['{"rank": 0, "world": 3, "gpus": 3, "steps": 2}']       # ONE line: rank 0's
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith('.seen')) == ['rank0.seen', 'rank1.seen', 'rank2.seen']
+
+
+def test_launcher_hands_the_masked_objective_to_every_rank(tmp_path):
+    """`python bench.py --gpus N --objective masked` (the north_star's data-parallel loop is the PRE-TRAIN step): the ranks see the objective
+    and the rest of the command line unchanged"""
+    r = _run_launcher(tmp_path, '''
+        import json
+        print(json.dumps(dict(rank=int(os.environ['RANK']), objective=args.objective, gpus=args.gpus, batch=args.batch)), flush=True)
+    ''', n=2, extra=('--objective', 'masked', '--batch', '64'))
+    assert r.returncode == 0, r.stderr
+    assert [l for l in r.stdout.splitlines() if l.startswith('{')] == ['{"rank": 0, "objective": "masked", "gpus": 2, "batch": 64}']
 
 
 def test_launcher_fails_when_a_rank_fails(tmp_path):

@@ -65,6 +65,50 @@ def test_rccl_path_on_one_rank_equals_plain_step(nccl_group):
         assert abs(n - ref_n) < 1e-2 * ref_n
 
 
+def _run_masked(steps, **kw):
+    m = E.MaskedEcgVit(_model(), mask_ratio=0.5).cuda().train()
+    x, _ = E.workload.synthetic_batch(24, length=5000, seed=3)
+    x = x.cuda()
+    idx = m.random_mask_indices(24, generator=torch.Generator().manual_seed(8))
+    st = E.HipTrainStep(m, dict(n_step=20, warmup_ratio=0.0), **kw)
+    torch.manual_seed(99)
+    losses = [float(st.step_masked(x, idx)[0]) for _ in range(steps)]
+    st.finish()
+    torch.cuda.synchronize()
+    return losses, m.encoder._pflat.clone(), st.grad_norm()
+
+
+def test_rccl_masked_step_on_one_rank_equals_plain_step(nccl_group):
+    """the MASKED pre-train step (the north_star's data-parallel loop is the pre-train step) under a process group: head bucket released at
+    the top of the backward pass, layer buckets from inside the trunk, embed + pretrain at its end -- through RCCL on one rank, both overlap
+    modes, bit-identical to the plain masked step with f32 on the wire"""
+    ref_l, ref_p, ref_n = _run_masked(3)
+    assert ref_l[2] < ref_l[0]
+    for kw in (dict(overlap_allreduce=False), dict(overlap_allreduce=True)):
+        l, p, n = _run_masked(3, single_rank_collectives=True, **kw)
+        assert l == ref_l and torch.equal(p, ref_p) and n == ref_n, kw
+    l, p, n = _run_masked(3, single_rank_collectives=True, grad_comm_dtype=BF16, overlap_allreduce=True)
+    assert all(abs(a - b) < 2e-3 * abs(b) + 1e-4 for a, b in zip(l, ref_l)), (l, ref_l)
+    assert float((p - ref_p).norm() / ref_p.norm()) < 1e-3
+
+
+def test_masked_backward_releases_buckets_in_ready_order(nccl_group):
+    """every bucket of the layout is reported exactly once per masked backward, `head` (zero for this objective) first"""
+    m = E.MaskedEcgVit(_model(), mask_ratio=0.5).cuda().train()
+    x, _ = E.workload.synthetic_batch(8, length=5000, seed=3)
+    idx = m.random_mask_indices(8, generator=torch.Generator().manual_seed(8))
+    eng = m.encoder._engine()
+    eng.forward_masked(x.cuda(), idx.cuda(), training=True, seed=1)
+    seen = []
+    eng.on_grads_ready = seen.append
+    try:
+        eng.backward_masked()
+    finally:
+        eng.on_grads_ready = None
+    want = [k for k, _ in m.encoder._layout.buckets_in_ready_order(eng.Ly)]
+    assert seen == want and seen[0] == 'head' and seen[-1] == 'pretrain', (seen, want)
+
+
 def test_grad_exchange_streams_on_gpu(nccl_group):
     """GradExchange alone on device buffers: buckets reduced on RCCL's stream while the producer stream keeps writing later buckets"""
     n = 1 << 22

@@ -238,13 +238,25 @@ def test_fp8_large_layer_shape_vs_cpu_oracle():
     assert all(v > 0 for v in fired.values()), fired          # the delayed scale update and every emitting producer ran in this pass
     assert first_use['fp8_amax'] == 0, first_use              # ... and no site took the first-use (own amax) path again
     hold_against_oracle(o8s, 'steady state (delayed scales, producers emit the 8-bit copies)')
-    # an eval forward in between does not move the scales a pending backward would read (advisor, round 3)
-    sc = eng.f8_scale.clone()
+    # EVAL passes follow the data too (advisor, round 4): an inference-only model must not keep its first batch's scales.  The first block's
+    # LayerNorm gain x 4 makes the QKV input (site 0) four times as large as anything the scales have seen: the pass after the first one on it
+    # runs with the scale grown to the new amax (with the old scale everything above the old amax was clamped), and its logits agree with
+    # the bf16 path's
+    m16 = E.EcgVit(config=conf, compute_dtype=BF16)
+    m16.load_state_dict(ref.state_dict())
+    m16.cuda().eval()
     m8.eval()
+    for mm in (m8, m16):
+        dict(mm.named_parameters())['vit.transformer.layers.0.0.norm.weight'].data.mul_(4.0)
+    sc = eng.f8_scale.clone()
     with torch.no_grad():
-        m8(sample_values=x.cuda())
+        m8(sample_values=x.cuda())                       # scales still from the pass before; its amax is recorded
+        l8 = m8(sample_values=x.cuda()).logits.clone()   # delayed scales from the pass above
+        l16 = m16(sample_values=x.cuda()).logits.clone()
+    assert 3.0 < float(eng.f8_scale[0]) / float(sc[0]) < 5.0, (float(eng.f8_scale[0]), float(sc[0]))
+    assert float((l8 - l16).abs().max()) < 0.2, float((l8 - l16).abs().max())
+    dict(m8.named_parameters())['vit.transformer.layers.0.0.norm.weight'].data.mul_(0.25)
     m8.train()
-    assert torch.equal(sc, eng.f8_scale)
 
 
 def test_full_large_fp8_configuration_properties():

@@ -379,6 +379,58 @@ def test_two_rank_data_parallel_step_equals_full_batch(tmp_path, overlap):
     assert abs(0.5 * (r0['losses'][1] + r1['losses'][1]) - float(loss)) < 1e-5
 
 
+def _ddp_masked_worker(rank, world, port, out_dir, overlap):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import ecg_representation_learning_amd as E
+    from oracle import vit_oracle as O
+    torch.cuda.set_device(0)
+    conf = E.EcgVitConfig(max_signal_length=400, patch_size=20, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          intermediate_size=128, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(11)
+    m = E.MaskedEcgVit(E.EcgVit(config=conf, compute_dtype=torch.float32), mask_ratio=0.5).cuda().train()
+    x, _ = O.synthetic_batch(8, length=400, seed=77)
+    idx = m.random_mask_indices(8, generator=torch.Generator().manual_seed(5))
+    lo, hi = E.ddp.shard_range(8, rank, world)
+    ts = E.HipTrainStep(m, dict(n_step=10, warmup_ratio=0.0, learning_rate=1e-3), sync_nonfinite=True, overlap_allreduce=overlap)
+    losses = []
+    for _ in range(2):
+        loss, _ = ts.step_masked(x[lo:hi].cuda(), idx[lo:hi])
+        losses.append(float(loss))
+    torch.save(dict(p=m.encoder._pflat.cpu(), norm=ts.grad_norm(), losses=losses), os.path.join(out_dir, f'm{rank}_{int(overlap)}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('overlap', [False, True])
+def test_two_rank_masked_step_equals_full_batch(tmp_path, overlap):
+    """the data-parallel MASKED pre-train step: two ranks on equal shards (their mean-L1 gradients summed, 1/world in the optimiser)
+    = one process on the whole batch, both overlap modes"""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_masked_worker, args=(2, port, str(tmp_path), overlap), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'm{r}_{int(overlap)}.pt')) for r in range(2))
+    assert torch.equal(r0['p'], r1['p'])
+    conf = E.EcgVitConfig(max_signal_length=400, patch_size=20, hidden_size=64, num_hidden_layers=2, num_attention_heads=4,
+                          intermediate_size=128, hidden_dropout_prob=0., attention_probs_dropout_prob=0.)
+    torch.manual_seed(11)
+    m = E.MaskedEcgVit(E.EcgVit(config=conf, compute_dtype=F32), mask_ratio=0.5).cuda().train()
+    x, _ = O.synthetic_batch(8, length=400, seed=77)
+    idx = m.random_mask_indices(8, generator=torch.Generator().manual_seed(5))
+    ts = E.HipTrainStep(m, dict(n_step=10, warmup_ratio=0.0, learning_rate=1e-3), sync_nonfinite=True)
+    for _ in range(2):
+        loss, _ = ts.step_masked(x.cuda(), idx)
+    assert abs(ts.grad_norm() - r0['norm']) / r0['norm'] < 1e-4
+    assert max_err(m.encoder._pflat, r0['p']) < 5e-6
+    assert abs(0.5 * (r0['losses'][1] + r1['losses'][1]) - float(loss)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------------ f2: fused input transforms
 def test_fused_input_transforms_match_reference_pipeline():
     """Normalize + TimeEndPad (+ TimeOut) fused into the patch gather == the reference's host pipeline (golden transforms.npz

@@ -174,6 +174,22 @@ def test_ptbxl_splits_multi_hot_and_feeder_order(tmp_path):
     assert torch.equal(allx, torch.from_numpy(rec[odd].astype(np.float32)))   # every record exactly once, in order
     per = (len(odd) + 2) // 3
     assert [sum(b['labels'].shape[0] for b in bs) for bs in ev] == [min(per, max(0, len(odd) - r * per)) for r in range(3)]
+    # a wrapped-around (pad=True) batch that names a record TWICE reaches the store as strictly increasing distinct indices (what HDF5's
+    # fancy indexing accepts) and is scattered back -- a store that rejects anything else, as h5py does:
+    class StrictStore:
+        shape, ndim = rec.shape, 3
+
+        def __getitem__(self, ix):
+            ix = np.asarray(ix)
+            assert ix.ndim == 1 and (np.diff(ix) > 0).all(), 'indices must be strictly increasing'
+            return rec[ix]
+    three = idx[:3]
+    fw = E.DeviceFeeder(StrictStore(), three, mh[three], 4, shuffle=False, device='cpu', rank=1, world=2)   # shard = [rec 2, rec 0] ; world 2 pads 3 -> 4
+    fw2 = E.DeviceFeeder(StrictStore(), three, mh[three], 4, shuffle=False, device='cpu', rank=0, world=1)
+    fw2.idxs = np.concatenate([fw2.idxs, fw2.idxs[:1]]); fw2.labels = np.concatenate([fw2.labels, fw2.labels[:1]])   # one batch naming record 0 twice
+    (b1,), (b2,) = list(fw), list(fw2)
+    assert torch.equal(b1['sample_values'], torch.from_numpy(rec[[three[2], three[0]]].astype(np.float32)))
+    assert torch.equal(b2['sample_values'], torch.from_numpy(rec[[three[0], three[1], three[2], three[0]]].astype(np.float32)))
     try:
         import h5py  # noqa: F401
     except ImportError:

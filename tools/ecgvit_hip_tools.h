@@ -18,13 +18,12 @@ int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *d
                                  int B, int N, int h, int dh, float scale, float dropout_p, uint64_t seed, int dtype,
                                  void *stream);
 
-/* >= 0: ecgvit_attention_bwd runs the eight-wave persistent kernels of rounds 1-3 (0 / 1: lockstep, 2: what round 3 shipped, 3 / 4 / 5:
- * priority variants); -1 (default): the shipped four-wave kernel.  tools/attn_variants.py, tools/attn_ab.py */
+/* -1 (default): the shipped eight-wave staggered persistent kernel; 0 .. 5: its lockstep / priority variants (0 / 1: lockstep, 2: what
+ * round 3 shipped, 3 / 4 / 5: priority variants).  tools/attn_variants.py, tools/attn_ab.py.  (-2 selected round 4's four-wave experiment
+ * while it was part of the tools build: tools/experiments/.) */
 int ecgvit_tools_attn_variant(int v);
 /* device buffer of 768 x 128 (+ per-phase records) uint64 that the eight-wave persistent backward fills with cycle stamps; NULL = off */
 int ecgvit_debug_attn_stamps(void *buf);
-/* device buffer of 768 x 4 x 128 uint64 that the four-wave backward (tools build) fills with the cycle stamps of every workgroup's second item; NULL = off */
-int ecgvit_tools_bwd4_stamps(void *buf);
 
 /* GEMM A/B and stamps (tools/gemm_ab.py, tools/nt_stamps.py, tools/contention.py, tools/wgrad_ab.py) */
 int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g, int diag);

@@ -27,6 +27,5 @@ def tools_lib():
         l.ecgvit_attention_bwd_oneitem.restype, l.ecgvit_attention_bwd_oneitem.argtypes = I, [P, P, P, P, P, I, I, I, I, F, F, U, I, P]
         l.ecgvit_tools_attn_variant.restype, l.ecgvit_tools_attn_variant.argtypes = I, [I]
         l.ecgvit_debug_attn_stamps.restype, l.ecgvit_debug_attn_stamps.argtypes = I, [P]
-        l.ecgvit_tools_bwd4_stamps.restype, l.ecgvit_tools_bwd4_stamps.argtypes = I, [P]
         _tools = l
     return _tools
