@@ -246,7 +246,9 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 // own up-front loads (bias, residual / aux rows) and BEFORE its first store: vmcnt retires in issue order, so pieces issued ahead of
 // those loads would have to land (an HBM round trip, with the matrix pipe idle) before the first row of the epilogue could start,
 // and pieces issued behind the stores would hold the next main loop until the stores are acknowledged.
-template <typename TO, int FL, int CAUX = 0, typename IssueNext>
+// ROLL: run a light body through the rolled loop as well (row loads one step ahead instead of all 16 up front): the four-wave kernel's
+// x-aux body -- with 256 accumulators live, 64 registers of aux rows on top of them are spilled
+template <typename TO, int FL, int CAUX = 0, bool ROLL = false, typename IssueNext>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gemm_desc &d, const EpiParams &e, const NtBufs &bf, int m0, int n0,
                                             int wave, int lane, IssueNext &&issue_next) {
     const int wm = wave >> 2, wn = wave & 3;
@@ -288,7 +290,7 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
     const int nbm = n0 + wn * 64 + 8 * (lane & 3);
     const bool nokm0 = nbm < N, nokm1 = nbm + 32 < N;
     constexpr bool kBf = sizeof(TO) == 2;
-    constexpr bool kLight = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
+    constexpr bool kLight = FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD)) && !ROLL;
     const bool want_res = kBf && NT_HAS(ECGVIT_EPI_RESIDUAL), want_aux = kBf && NT_HAS(ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_GELU_BWD);
     // rows >= M fall beyond num_records by themselves; masked columns are forced there
     auto ld_res = [&](int i, int h) {
@@ -845,6 +847,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
     // second half's row loads
     constexpr int NST = 2 * (sizeof(TO) == 2 ? 16 : 32) + ((FL & ECGVIT_EPI_RESIDUAL) ? 16 : 0) + ((FL & ECGVIT_EPI_MUL_AUX) ? 16 : 0);
     static_assert(FL >= 0 && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_ACCUM | ECGVIT_EPI_QUANT_OUT)) && 8 + NST <= 63, "light bodies only");
+    constexpr bool kRoll = (FL & ECGVIT_EPI_MUL_AUX) != 0;
     [[maybe_unused]] unsigned long long st_t0 = 0, st_r0 = 0, st_main = 0, st_epi = 0, st_ntile = 0;
 #ifdef ECGVIT_TOOLS
     if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -917,8 +920,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel_4w(ecgvit_gemm_desc d, 
         int eln;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(eln));
         bf.t_out = ((eln >> 2) + 16 * (eln & 3)) << 2;
-        nt_epilogue<TO, FL, CAUX>(acc[0], d, e, bf, cm0, cn0, 4 * wm + 2 * wn, eln, issue_next);
-        nt_epilogue<TO, FL, CAUX>(acc[1], d, e, bf, cm0, cn0, 4 * wm + 2 * wn + 1, eln, none);
+        nt_epilogue<TO, FL, CAUX, kRoll>(acc[0], d, e, bf, cm0, cn0, 4 * wm + 2 * wn, eln, issue_next);
+        nt_epilogue<TO, FL, CAUX, kRoll>(acc[1], d, e, bf, cm0, cn0, 4 * wm + 2 * wn + 1, eln, none);
         }
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
         if (!has_next) break;
@@ -1113,7 +1116,8 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
     const int fl = d->epilogue;
     if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || d->K < 192 || e.alpha != 1.f || d->scale_a || d->scale_b) return ECGVIT_EINVAL;
     // (the FFN-down input gradient's body -- x aux, column sums -- measured 1,044 us on this body against 696: 288 B of spills, one wave's VALU)
-    if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT)) return ECGVIT_EINVAL;
+    constexpr int F_DH = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM;
+    if (fl != 0 && fl != F_LIN && fl != (F_LIN | ECGVIT_EPI_DROPOUT) && fl != F_DH) return ECGVIT_EINVAL;
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN, ntile = tiles_m * tiles_n;
     const int G = raster_g > 0 ? std::min(raster_g, tiles_n) : nt_default_group(tiles_n);
     const int tpw = d->tiles_per_workgroup;   // > 0: dispatcher-balanced chunks of ~tpw tiles, as in ecgvit_gemm_nt_launch
@@ -1129,10 +1133,15 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
 #endif
     if (fl == F_LIN) NT4W_GO(F_LIN, 0, false, 0);
     else if (fl == (F_LIN | ECGVIT_EPI_DROPOUT)) NT4W_GO(F_LIN | ECGVIT_EPI_DROPOUT, 0, false, 0);
+    else if (fl == F_DH) NT4W_GO(F_DH, 0, false, 0);
     else if (diag & 2) NT4W_GO(0, 2, false, 0);
     else NT4W_GO(0, 0, false, 0);
 #undef NT4W_GO
     ECGVIT_CHECK_LAUNCH();
+    if (fl & ECGVIT_EPI_COLSUM) {
+        ecgvit_colsum_reduce_launch((const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out, s);
+        ECGVIT_CHECK_LAUNCH();
+    }
     return ECGVIT_OK;
 }
 

@@ -85,7 +85,7 @@ def main():
         if args.nt4 and epi == 0:
             variants.append(('4w', 3, 0, 0))
             variants.append(('4w nt', 3, 0, 2))
-        if args.nt4 and epi == LIN:
+        if args.nt4 and epi in (LIN, DH):
             variants.append(('4w', 3, 0, 0))
         C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
         A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
