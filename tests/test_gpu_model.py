@@ -427,7 +427,9 @@ def test_two_rank_masked_step_equals_full_batch(tmp_path, overlap):
     for _ in range(2):
         loss, _ = ts.step_masked(x.cuda(), idx)
     assert abs(ts.grad_norm() - r0['norm']) / r0['norm'] < 1e-4
-    assert max_err(m.encoder._pflat, r0['p']) < 5e-6
+    # two AdamW steps at lr 1e-3: an update is lr * m / (sqrt(v) + eps), so the f32 summation-order difference between "two shard sums added"
+    # and "one sum over the batch" moves a weight by at most a few per cent of ONE step where the gradient is tiny (L1's sign gradients)
+    assert max_err(m.encoder._pflat, r0['p']) < 2e-5
     assert abs(0.5 * (r0['losses'][1] + r1['losses'][1]) - float(loss)) < 1e-5
 
 
