@@ -1,5 +1,5 @@
-// Tile walk shared by the persistent A . B^T kernels (gemm_nt.hip: the eight- and four-wave bodies; gemm_ov.hip: the four-wave body with the
-// deferred epilogue): 256 x 256 output tiles, dealt XCD-contiguously over column groups of G n-tiles.
+// Tile walk of the persistent A . B^T kernels (gemm_nt.hip: the eight- and four-wave bodies; tools/experiments/gemm_ov.hip: round 5's four-wave body
+// with the deferred epilogue): 256 x 256 output tiles, dealt XCD-contiguously over column groups of G n-tiles.
 #pragma once
 #include "common.h"
 
