@@ -54,11 +54,16 @@ CONFIGS = {
 
 
 def dropout_desc(conf):
-    """dropout as APPLIED: hidden / embedding sites at p rounded to 1/65536; the fused attention kernels draw 8 bits per key, so the
-    attention-probability dropout runs at round(256 p)/256 (0.1 -> 26/256 = 0.1016), kept values rescaled by the exact keep rate"""
+    """dropout as APPLIED by the bf16 path: every site draws 8 bits per element (one hash per four consecutive elements; the fused attention
+    kernels: per four keys), so p runs at round(256 p)/256 (0.1 -> 26/256 = 0.1016), kept values rescaled by the exact keep rate; the f32
+    parity path applies the exact p"""
     p, pa = conf.hidden_dropout_prob, conf.attention_probs_dropout_prob
-    t = min(255, int(pa * 256.0 + 0.5)) if pa > 0 else 0
-    return f'dropout {p:g} (hidden / embedding), attention-probability dropout applied at {t}/256 = {t / 256:.4f} (configured {pa:g})'
+
+    def q(v):
+        t = min(255, int(v * 256.0 + 0.5)) if v > 0 else 0
+        return f'{t}/256 = {t / 256:.4f}'
+    return (f'hidden dropout applied at {q(p)} (configured {p:g}), embedding dropout at {q(pa)}, attention-probability dropout at {q(p)} '
+            f'(bf16 path: 8 random bits per element)')
 
 
 def make_config(E, name, patch, length, dropout):

@@ -123,31 +123,55 @@ __device__ __forceinline__ void dropout_pair(uint64_t seed, uint32_t idx0, uint3
     m0 = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
     m1 = (h >> 16) >= thresh ? inv_keep : 0.f;
 }
-// returns the multiplier: 0 or 1/(1-p)
-__device__ __forceinline__ float dropout_mult(uint64_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
-    const uint32_t h = pair_hash(seed, idx);
-    const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
-    return r >= thresh ? inv_keep : 0.f;
+// ---- the bf16 path's hidden / embedding dropout (round 5): ONE hash per FOUR consecutive elements, 8 random bits each (byte b of the hash of
+// quad idx / 4 belongs to element idx % 4), keep iff byte >= round(256 p) -- the form the fused attention kernels use since round 2, now for
+// every 16-bit dropout site: half the hashes of the pair form, and the keep decision of a whole quad in three bit-parallel instructions.  p is
+// applied as round(256 p) / 256 (0.1 -> 0.1016) and rescaled by the exact keep rate 256 / (256 - t): dropout_threshold8 / dropout_inv_keep8
+// (0 < p < 1/512 would round to no dropout: the host side rejects it).  The f32 parity path keeps the pair form at the exact p (16 bits).
+// quad_keepbits: bit 7 of byte b = keep(element b).  a >= t for bytes: with t < 128 it is a7 | (a_lo >= t_lo), else a7 & (a_lo >= t_lo), and
+// bit 7 of (a_lo + 0x80 - t_lo) is (a_lo >= t_lo) without a carry into the next byte.  c4 = (0x80 - (t & 0x7F)) in every byte.
+__device__ __forceinline__ uint32_t quad_c4(uint32_t t8) { return (0x80u - (t8 & 0x7Fu)) * 0x01010101u; }
+__device__ __forceinline__ uint32_t quad_keepbits(uint32_t h, uint32_t c4, bool t_hi) {
+    const uint32_t x1 = (h & 0x7F7F7F7Fu) + c4;
+    return t_hi ? (x1 & h) : (x1 | h);
 }
-// multipliers of VN (4 or 8) consecutive elements starting at an EVEN index: one Weyl multiply, VN/2 finishers
-template <int VN> __device__ __forceinline__ void dropout_maskN(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[VN]) {
-    const uint32_t base = pair_base(seed, idx0);
-#pragma unroll
-    for (int k = 0; k < VN / 2; ++k) {
-        const uint32_t h = pair_finish(base + (uint32_t)k * ECGVIT_WEYL);
-        m[2 * k] = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
-        m[2 * k + 1] = (h >> 16) >= thresh ? inv_keep : 0.f;
+__device__ __forceinline__ uint32_t quad_base(uint64_t seed, uint32_t idx) { return (idx >> 2) * ECGVIT_WEYL + seed_mix(seed); }
+// returns the multiplier: 0 or 1/(1-p).  Q8: the quad form (thresh = 8-bit threshold), else the pair form (16-bit threshold)
+template <bool Q8> __device__ __forceinline__ float dropout_mult(uint64_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
+    if constexpr (Q8) {
+        const uint32_t h = pair_finish(quad_base(seed, idx));
+        return ((h >> (8 * (idx & 3))) & 0xFFu) >= thresh ? inv_keep : 0.f;
+    } else {
+        const uint32_t h = pair_hash(seed, idx);
+        const uint32_t r = (idx & 1) ? (h >> 16) : (h & 0xFFFFu);
+        return r >= thresh ? inv_keep : 0.f;
     }
 }
-__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[8]) {
-    dropout_maskN<8>(seed, idx0, thresh, inv_keep, m);
-}
-// 8 consecutive values starting at an EVEN index, multiplied in place
-__device__ __forceinline__ void dropout_mult8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&v)[8]) {
-    float m[8];
-    dropout_maskN<8>(seed, idx0, thresh, inv_keep, m);
+// multipliers of VN (4 or 8) consecutive elements starting at a multiple of 4: one Weyl multiply, VN/2 (pair form) or VN/4 (quad form) finishers
+template <int VN, bool Q8> __device__ __forceinline__ void dropout_maskN(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[VN]) {
+    if constexpr (Q8) {
+        const uint32_t base = quad_base(seed, idx0), c4 = quad_c4(thresh), ik = __float_as_uint(inv_keep);
+        const bool t_hi = thresh >= 128u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] *= m[k];
+        for (int q = 0; q < VN / 4; ++q) {
+            const uint32_t x = quad_keepbits(pair_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)   // the keep bit spread over the dword (v_bfe_i32), ANDed into the multiplier's bits
+                m[4 * q + b] = __uint_as_float(ik & (uint32_t)__builtin_amdgcn_sbfe((int)x, 8 * b + 7, 1));
+        }
+    } else {
+        const uint32_t base = pair_base(seed, idx0);
+#pragma unroll
+        for (int k = 0; k < VN / 2; ++k) {
+            const uint32_t h = pair_finish(base + (uint32_t)k * ECGVIT_WEYL);
+            m[2 * k] = (h & 0xFFFFu) >= thresh ? inv_keep : 0.f;
+            m[2 * k + 1] = (h >> 16) >= thresh ? inv_keep : 0.f;
+        }
+    }
+}
+// the bf16 epilogues' run of 8 (quad form)
+__device__ __forceinline__ void dropout_mask8(uint64_t seed, uint32_t idx0, uint32_t thresh, float inv_keep, float (&m)[8]) {
+    dropout_maskN<8, true>(seed, idx0, thresh, inv_keep, m);
 }
 // ---- attention-probability dropout: one hash per FOUR consecutive keys of a query, 8 random bits each (threshold = round(p * 256),
 // as FlashAttention's kernels quantise p; the kept values are rescaled by the exact 256 / (256 - threshold), so the estimator stays
@@ -163,6 +187,21 @@ static inline uint32_t dropout_threshold8(float p) {
 }
 static inline float dropout_inv_keep8(float p) { return 256.0f / (256.0f - (float)dropout_threshold8(p)); }
 
+static inline uint32_t dropout_threshold(float p);
+// threshold and rescale of a hidden / embedding dropout site: 16-bit element types take the quad mask (8-bit threshold; false: p would round to
+// no dropout), f32 the pair mask at the exact p
+static inline bool dropout_site_params(float p, bool q8, uint32_t &thresh, float &inv_keep) {
+    if (p <= 0.f) { thresh = 0u; inv_keep = 1.f; return true; }
+    if (q8) {
+        thresh = dropout_threshold8(p);
+        inv_keep = dropout_inv_keep8(p);
+        return thresh != 0u;
+    }
+    thresh = dropout_threshold(p);
+    inv_keep = 1.0f / (1.0f - p);
+    return true;
+}
+
 static inline uint32_t dropout_threshold(float p) {
     if (p <= 0.f) return 0u;
     double t = (double)p * 65536.0 + 0.5;
@@ -170,21 +209,24 @@ static inline uint32_t dropout_threshold(float p) {
     return (uint32_t)t;
 }
 
-// ---- bf16-path GELU: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16's 2^-8), one exp + one rcp;
+// ---- bf16-path GELU: erf by Abramowitz-Stegun 7.1.25 (three terms, |err| <= 2.5e-5: an absolute error of 1.3e-5 in Phi, i.e. <= 5e-5 in
+//      GELU at |x| = 4 where one bf16 ulp of the result is 0.016 -- far below the rounding of the stored value; round 4 used 7.1.26's five terms
+//      at 1.5e-7, two fma per element more in epilogues that are bound by vector-instruction issue), one exp + one rcp;
 //      GELU' reuses the same exponential (erf(x/sqrt2) is built on e^{-x^2/2} = sqrt(2 pi) * pdf).
 //      ONE formulation for every kernel (the 128^2 GEMM, the persistent GEMM, the split-K reducer): the same record must produce the
 //      same bits whichever kernel its batch size selects (eval logits are batch-slice invariant: tests/test_gpu_model.py).
+//      The f32 parity path does not come here (erff / expf: gelu_erf, gelu_erf_grad).
 //      cdf_k = k * Phi(x), pdf_k = k * phi(x) for a wave-uniform k >= 0 passed as hk = k/2, ck = k/sqrt(2 pi): the FFN-up epilogue
 //      folds the dropout rescale 1/(1-p) in here; everything else passes k = 1.  |x| is a source modifier and the exponential is
-//      taken as 2^(-u^2), u = |x| sqrt(log2(e)/2): 14 VALU instructions for both parts.
+//      taken as 2^(-u^2), u = |x| sqrt(log2(e)/2): 12 VALU instructions for both parts.
 #define ECGVIT_GELU_HK1 0.5f
 #define ECGVIT_GELU_CK1 0.39894228040143267794f
 __device__ __forceinline__ void gelu_fast_parts_scaled(float x, float hk, float ck, float &cdf, float &pdf) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));   // v_rcp_f32 (1 ulp)
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.47047f * 0.70710678118654752440f, 1.0f));   // v_rcp_f32 (1 ulp)
     const float u = ax * 0.84932180028801904272f;
     const float ex = __builtin_amdgcn_exp2f(-u * u);   // = e^{-x^2/2}
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float poly = t * (0.3480242f + t * (-0.0958798f + t * 0.7478556f));
     const float s = copysignf(fmaf(-poly, ex, 1.0f), x);   // erf(x / sqrt 2)
     cdf = fmaf(hk, s, hk);
     pdf = ck * ex;
@@ -201,21 +243,23 @@ __device__ __forceinline__ void gelu_fast_both_scaled(float x, float hk, float c
     dy = fmaf(x, p, c);
 }
 
-// Drop mask of the pair of consecutive elements hashed to h, as a dword: 0xFFFF in the half of a DROPPED element (half < thresh,
-// unsigned), 0 in the half of a kept one -- packed 16-bit arithmetic on the two halves at once: h ^ 0x80008000 maps the unsigned
-// order onto the signed one, a saturating signed subtract of the (equally flipped) threshold keeps the sign of the difference, an
-// arithmetic shift spreads it.  The same keep set as dropout_pair(), three instructions per PAIR, applied to packed bf16 results with
-// one AND-NOT each (the rescale 1/(1-p) is folded into the values beforehand).  tflip2 = ((thresh ^ 0x8000) & 0xFFFF) * 0x10001.
+// KEEP masks of 8 consecutive elements (a multiple of 4) for PACKED bf16 pairs (quad form): dword k = pair (2k, 2k + 1): 0xFFFF in the half of
+// a kept element.  Per quad the keep bits (3 instructions), per pair one byte permute that puts the two keep bits at the halves' sign
+// positions and one packed arithmetic shift that spreads them: the same keep set as dropout_maskN<8, true>, applied to packed results
+// with one AND each (the rescale 1/(1-p) is folded into the values beforehand).
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t dropmask_of_pair(uint32_t h, uint32_t tflip2) {
-    const s16x2_t d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, h ^ 0x80008000u), __builtin_bit_cast(s16x2_t, tflip2));
-    return __builtin_bit_cast(uint32_t, d >> (s16x2_t){15, 15});
-}
-// drop masks of 8 consecutive elements starting at an EVEN index: the pairs of dropout_maskN<8>
-__device__ __forceinline__ void dropmask8(uint64_t seed, uint32_t idx0, uint32_t tflip2, uint32_t (&m)[4]) {
-    const uint32_t base = pair_base(seed, idx0);
+__device__ __forceinline__ void keepmask8(uint64_t seed, uint32_t idx0, uint32_t thresh, uint32_t (&m)[4]) {
+    const uint32_t base = quad_base(seed, idx0), c4 = quad_c4(thresh);
+    const bool t_hi = thresh >= 128u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) m[k] = dropmask_of_pair(pair_finish(base + (uint32_t)k * ECGVIT_WEYL), tflip2);
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t x = quad_keepbits(pair_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const uint32_t w = __builtin_amdgcn_perm(x, x, pp ? 0x030C020Cu : 0x010C000Cu);   // bytes (2pp, 2pp + 1) -> the high bytes of the two halves
+            m[2 * q + pp] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, w) >> (s16x2_t){15, 15});
+        }
+    }
 }
 
 // ---- epilogue parameters shared by the f32 and bf16 GEMMs -------------------------------------
@@ -237,7 +281,7 @@ struct EpiParams {
 template <typename TO> __device__ __forceinline__ float epilogue_value(float acc, int64_t m, int n, const EpiParams &e) {
     float v = acc * e.alpha;
     if (e.flags & ECGVIT_EPI_BIAS) v += e.bias[n];
-    const float mult = (e.flags & ECGVIT_EPI_DROPOUT) ? dropout_mult(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep) : 1.f;
+    const float mult = (e.flags & ECGVIT_EPI_DROPOUT) ? dropout_mult<sizeof(TO) == 2>(e.seed, (uint32_t)m * (uint32_t)e.N + (uint32_t)n, e.drop_thresh, e.inv_keep) : 1.f;
     if (e.flags & ECGVIT_EPI_GELU) {
         if (e.flags & ECGVIT_EPI_GELU_GRAD_AUX) {
             reinterpret_cast<TO *>(e.aux)[m * e.ldaux + n] = from_f32<TO>(gelu_erf_grad(v) * mult);
@@ -265,8 +309,10 @@ static inline EpiParams make_epi(const ecgvit_gemm_desc *d) {
     e.ldaux = d->ldaux;
     e.alpha = d->alpha;
     e.seed = d->dropout_seed;
-    e.drop_thresh = dropout_threshold(d->dropout_p);
-    e.inv_keep = d->dropout_p > 0.f ? 1.0f / (1.0f - d->dropout_p) : 1.0f;
+    // 16-bit outputs: the quad mask (8-bit threshold, exact rescale of round(256 p) / 256); f32 outputs (parity path): the pair mask at the exact p
+    const bool q8 = d->out_dtype == ECGVIT_BF16;
+    e.drop_thresh = q8 ? dropout_threshold8(d->dropout_p) : dropout_threshold(d->dropout_p);
+    e.inv_keep = d->dropout_p > 0.f ? (q8 ? dropout_inv_keep8(d->dropout_p) : 1.0f / (1.0f - d->dropout_p)) : 1.0f;
     e.N = d->N;
     return e;
 }

@@ -131,8 +131,8 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         for (int k = 0; k < 8; ++k) v[k] += bias8[k];
     }
     // FFN-up forward (bias + erf-GELU + saved GELU' x mask [+ dropout]): the launch whose epilogue is VALU-bound.  The dropout rescale is
-    // folded into the GELU constants and the mask is applied to the PACKED results (drop masks from packed 16-bit arithmetic,
-    // one AND-NOT per result dword): 22 instead of 27 VALU instructions per element; the keep set is dropout_mask8's bit for bit
+    // folded into the GELU constants and the mask is applied to the PACKED results (keep masks of the quad form: one hash per four elements,
+    // one AND per result dword); the keep set is dropout_mask8's bit for bit
     constexpr bool kUp = sizeof(TO) == 2 && FL >= 0 && (FL & ECGVIT_EPI_GELU) && (FL & ECGVIT_EPI_GELU_GRAD_AUX) &&
                          !(FL & (ECGVIT_EPI_GELU_BWD | ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_RESIDUAL | ECGVIT_EPI_ACCUM));
     if constexpr (kUp) {
@@ -146,10 +146,10 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 #pragma unroll
         for (int k = 0; k < 4; ++k) { sav[k] = pack_bf16x2(dy[2 * k], dy[2 * k + 1]); out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]); }
         if constexpr (kDrop) {
-            uint32_t dm[4];
-            dropmask8(e.seed, m * (uint32_t)e.N + ncol, ((e.drop_thresh ^ 0x8000u) & 0xFFFFu) * 0x10001u, dm);
+            uint32_t km[4];
+            keepmask8(e.seed, m * (uint32_t)e.N + ncol, e.drop_thresh, km);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { sav[k] &= ~dm[k]; out[k] &= ~dm[k]; }
+            for (int k = 0; k < 4; ++k) { sav[k] &= km[k]; out[k] &= km[k]; }
         }
         __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
         if constexpr (!(FL & ECGVIT_EPI_NO_OUT))   // (NO_OUT: the consumers read the 8-bit copy only)

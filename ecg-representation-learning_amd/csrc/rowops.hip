@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void embed_finish_kernel(const T *__restrict__
         }
         if (thresh) {
             float mk[VN];   // d and c0 are multiples of VN: the run starts on an even element
-            dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
+            dropout_maskN<VN, sizeof(T) == 2>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
 #pragma unroll
             for (int k = 0; k < VN; ++k) o.set(k, o.get(k) * mk[k]);
         }
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const T *__restrict__ dX
             Vec16<T> v = ld16(dX + row * d + c0);
             if (thresh) {
                 float mk[VN];
-                dropout_maskN<VN>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
+                dropout_maskN<VN, sizeof(T) == 2>(seed, (uint32_t)row * (uint32_t)d + (uint32_t)c0, thresh, inv_keep, mk);
 #pragma unroll
                 for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
             }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T *__restrict_
                     if (thresh) {
                         Vec16<T> om;
                         float mk[VN];
-                        dropout_maskN<VN>(seed, (uint32_t)r * (uint32_t)d + (uint32_t)c, thresh, inv_keep, mk);
+                        dropout_maskN<VN, sizeof(T) == 2>(seed, (uint32_t)r * (uint32_t)d + (uint32_t)c, thresh, inv_keep, mk);
 #pragma unroll
                         for (int k = 0; k < VN; ++k) om.set(k, o.get(k) * mk[k]);
                         st16(dxm + r * d + c, om);
@@ -466,13 +466,13 @@ __global__ __launch_bounds__(256, E <= 12 ? 4 : 2) void layernorm_bwd_fit_kernel
 #pragma unroll
                 for (int i = 0; i < L::N16; ++i) {
                     float mk[8];
-                    dropout_maskN<8>(seed, ro + (uint32_t)((i * 64 + lane) * 8), thresh, inv_keep, mk);
+                    dropout_maskN<8, true>(seed, ro + (uint32_t)((i * 64 + lane) * 8), thresh, inv_keep, mk);
 #pragma unroll
                     for (int k = 0; k < 8; ++k) o[8 * i + k] = (float)(bf16_t)(o[8 * i + k] * mk[k]);
                 }
                 if constexpr (L::N8 == 1) {
                     float mk[4];
-                    dropout_maskN<4>(seed, ro + (uint32_t)(512 * L::N16 + 4 * lane), thresh, inv_keep, mk);
+                    dropout_maskN<4, true>(seed, ro + (uint32_t)(512 * L::N16 + 4 * lane), thresh, inv_keep, mk);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) o[8 * L::N16 + k] = (float)(bf16_t)(o[8 * L::N16 + k] * mk[k]);
                 }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const T *__restrict_
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nv; i += (int64_t)gridDim.x * 256) {
         Vec16<T> v = ld16(in + i * VN);
         float mk[VN];
-        dropout_maskN<VN>(seed, (uint32_t)i * (uint32_t)VN, thresh, inv_keep, mk);
+        dropout_maskN<VN, sizeof(T) == 2>(seed, (uint32_t)i * (uint32_t)VN, thresh, inv_keep, mk);
 #pragma unroll
         for (int k = 0; k < VN; ++k) v.set(k, v.get(k) * mk[k]);
         st16(out + i * VN, v);
@@ -677,8 +677,9 @@ int ecgvit_patch_gather_transform(const float *x_raw, void *patches, int B, int 
 int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, void *X, int B, int n, int d, float dropout_p,
                         uint64_t seed, int dtype, void *stream) {
     if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    uint32_t th;
+    float ik;
+    if (!dropout_site_params(dropout_p, dtype == ECGVIT_BF16, th, ik)) return ECGVIT_EINVAL;   // (bf16: p applied as round(256 p) / 256; below 1/512: rejected)
     const int64_t total = (int64_t)B * (n + 1) * d / (dtype == ECGVIT_F32 ? 4 : 8);
     const int grid = (int)std::min<int64_t>((total + 255) / 256, 4096);
     if (dtype == ECGVIT_F32)
@@ -693,8 +694,9 @@ int ecgvit_embed_finish(const void *tok, const float *cls, const float *pos, voi
 int ecgvit_embed_bwd(const void *dX, void *dtok, float *dcls, float *dpos, int B, int n, int d, float dropout_p, uint64_t seed,
                      int dtype, void *stream) {
     if (B <= 0 || n <= 0 || d <= 0 || d % 8 != 0) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    uint32_t th;
+    float ik;
+    if (!dropout_site_params(dropout_p, dtype == ECGVIT_BF16, th, ik)) return ECGVIT_EINVAL;   // (bf16: p applied as round(256 p) / 256; below 1/512: rejected)
     const int dv = d / (dtype == ECGVIT_F32 ? 4 : 8);
     const int grid = (n + 1) * ((dv + 7) / 8);   // one block per (token, group of 8 column chunks)
     if (dtype == ECGVIT_F32)
@@ -754,8 +756,9 @@ static int ln_bwd_launch(const void *dy, const void *x, const float *gamma, cons
     const int np = extra ? 3 : 2;
     const size_t lds = (size_t)4 * np * d * 4;
     if (dtype != ECGVIT_F32 && dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    uint32_t th;
+    float ik;
+    if (!dropout_site_params(dropout_p, dtype == ECGVIT_BF16, th, ik)) return ECGVIT_EINVAL;   // (bf16: p applied as round(256 p) / 256; below 1/512: rejected)
     if (dtype == ECGVIT_BF16 && ln_fit(d) && (int64_t)rows * d < (1ll << 31)) {
         const size_t ldsf = lds + (size_t)d * 4;   // + gamma
 #define LN_FIT(EE)                                                                                                                \
@@ -828,8 +831,9 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
 
 int ecgvit_dropout_apply(const void *in, void *out, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream) {
     if (count <= 0 || count % 8 != 0) return ECGVIT_EINVAL;
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ik = dropout_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+    uint32_t th;
+    float ik;
+    if (!dropout_site_params(dropout_p, dtype == ECGVIT_BF16, th, ik)) return ECGVIT_EINVAL;   // (bf16: p applied as round(256 p) / 256; below 1/512: rejected)
     const int grid = (int)std::min<int64_t>((count / 4 + 255) / 256, 4096);
     if (dtype == ECGVIT_F32)
         hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float *)in, (float *)out, count, seed, th, ik);

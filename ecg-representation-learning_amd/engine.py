@@ -100,10 +100,11 @@ class VitEngine:
                 raise ValueError(f'bf16 fused attention needs head dim 64 (got {self.dh}); use dtype=torch.float32')
             if self.N > 512:
                 raise ValueError(f'bf16 fused attention covers <= 512 tokens (got {self.N}); use dtype=torch.float32')
-            if 0.0 < self.p_hidden < 1.0 / 512:
-                # the fused attention kernels draw 8 random bits per key: p is applied as round(256 p) / 256 (0.1 -> 0.1016)
-                raise ValueError(f'bf16 fused attention applies dropout in steps of 1/256: hidden_dropout_prob={self.p_hidden} would round '
-                                 f'to no dropout; use 0, a value >= 1/512, or compute_dtype=torch.float32 (exact p)')
+            for nm, pv in (('hidden_dropout_prob', self.p_hidden), ('attention_probs_dropout_prob (the embedding dropout: reference ecg_vit.py:113)', self.p_emb)):
+                if 0.0 < pv < 1.0 / 512:
+                    # every dropout site of the bf16 path draws 8 random bits per element: p is applied as round(256 p) / 256 (0.1 -> 0.1016)
+                    raise ValueError(f'the bf16 path applies dropout in steps of 1/256: {nm}={pv} would round to no dropout; use 0, a value '
+                                     f'>= 1/512, or compute_dtype=torch.float32 (exact p)')
         # fp8 Linear operands (BASELINE.json configs[4]): every product of the four block Linears takes 8-bit operands -- forward e4m3 x e4m3,
         # input gradients e5m2 gradients x e4m3 weights, weight gradients e5m2 gradients x e4m3 activations with f32 split-K accumulation
         # (per-tensor scales, delayed for activations and gradients); attention, LayerNorm and the optimiser stay bf16 / f32

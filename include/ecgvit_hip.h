@@ -57,8 +57,11 @@ int ecgvit_abi_version(void);
 #define ECGVIT_EPI_GELU_BWD 4   /* v *= gelu_erf'(aux[m,n])                                          */
 #define ECGVIT_EPI_RESIDUAL 8   /* v += residual[m,n]                                                */
 #define ECGVIT_EPI_ACCUM 16     /* v += C[m,n]   (read-modify-write of the output)                   */
-#define ECGVIT_EPI_DROPOUT 32   /* v = keep(seed, m*N+n) ? v / (1-p) : 0 ; applied after GELU / GELU_BWD,
-                                   before RESIDUAL (the mask is a pure function of (seed, element))   */
+#define ECGVIT_EPI_DROPOUT 32   /* v = keep(seed, m*N+n) ? v / (1-p') : 0 ; applied after GELU / GELU_BWD,
+                                   before RESIDUAL (the mask is a pure function of (seed, element)).  bf16 outputs: one hash per four
+                                   consecutive elements, 8 bits each: p' = round(256 p) / 256 (0 < p < 1/512: ECGVIT_EINVAL); f32 outputs:
+                                   one hash per pair, 16 bits each: p' = p.  The same rule holds for every dropout_p of this header
+                                   (ecgvit_embed_finish / _bwd, ecgvit_layernorm_bwd_fused, ecgvit_dropout_apply): by element type        */
 #define ECGVIT_EPI_GELU_GRAD_AUX 128 /* modifies EPI_GELU: aux[m,n] = gelu_erf'(v) * (the EPI_DROPOUT multiplier of this element, if any)
                                    instead of v -- everything the backward of `dropout(gelu(.))` needs, so that the input-gradient GEMM
                                    of the next Linear finishes with EPI_MUL_AUX alone (no erf, no mask hash in the backward)    */

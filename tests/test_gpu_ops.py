@@ -827,7 +827,7 @@ def test_gemm_bf16_saved_gelu_grad_and_mul_aux(shape):
 
 
 def test_dropout_mask_statistics():
-    """the counter-based mask (one Weyl step + one xorshift-multiply round per pair of elements): keep rate, independence of neighbours
+    """the f32 parity path's counter-based mask (one Weyl step + one xorshift-multiply round per pair of elements, exact p): keep rate, independence of neighbours
     along a row, across rows and across seeds -- on 4M elements the standard error of a correlation is 5e-4"""
     rows, d = 4096, 1024
     ones = torch.ones(rows * d, device='cuda')
@@ -853,6 +853,88 @@ def test_dropout_mask_statistics():
         masks.append(keep)
     z0, z1 = masks[0] - masks[0].mean(), masks[1] - masks[1].mean()
     assert abs(float((z0 * z1).mean()) / float((z0 * z0).mean())) < 4e-3   # seeds 1 and 2: unrelated masks
+
+
+def test_dropout_mask_statistics_bf16_quad_form():
+    """the 16-bit sites' mask (round 5): one hash per FOUR consecutive elements, 8 bits each, keep iff byte >= round(256 p), exact rescale of the rate
+    actually applied.  Keep rate, value of the kept elements, independence inside a quad (bytes of one hash), across quads, rows and seeds;
+    thresholds on both sides of 128 (the bit-parallel compare has two forms) and the smallest one; 0 < p < 1/512 is an error, not "no dropout"."""
+    rows, d = 4096, 1024
+    ones = torch.ones(rows * d, device='cuda', dtype=BF16)
+    masks = []
+    for p, seed in ((0.1, 1), (0.1, 2), (0.5, 123456789012345), (0.75, 7), (1.0 / 256, 3), (0.3, 11)):
+        t8 = min(255, int(p * 256 + 0.5))
+        pa = t8 / 256.0
+        out = torch.empty_like(ones)
+        check(lib().ecgvit_dropout_apply(ptr(ones), ptr(out), rows * d, p, seed, hip.BF16, stream()), 'dropout_apply')
+        keep = (out != 0).float().view(rows, d)
+        assert abs(float(keep.mean()) - (1 - pa)) < 1.5e-3, (p, float(keep.mean()))
+        kept = out[out != 0].float()
+        assert float((kept - 1.0 / (1 - pa)).abs().max()) <= 2.0 ** -8 / (1 - pa)      # 256 / (256 - t), rounded to bf16 once
+        z = keep - keep.mean()
+        var = float((z * z).mean())
+
+        def corr(a, b):
+            return float((a * b).mean()) / var
+        for lag in (1, 2, 3, 4, 8, 64):                                # lags 1-3: mostly the same hash word; 4: the next Weyl step
+            assert abs(corr(z[:, :-lag], z[:, lag:])) < 5e-3, (p, lag)
+        assert abs(corr(z[:-1, :], z[1:, :])) < 5e-3
+        colmean, rowmean = keep.mean(0), keep.mean(1)
+        assert float((colmean - (1 - pa)).abs().max()) < 5 * (pa * (1 - pa) / rows) ** 0.5 + 1e-3
+        assert float((rowmean - (1 - pa)).abs().max()) < 5 * (pa * (1 - pa) / d) ** 0.5 + 1e-3
+        masks.append(keep)
+    z0, z1 = masks[0] - masks[0].mean(), masks[1] - masks[1].mean()
+    assert abs(float((z0 * z1).mean()) / float((z0 * z0).mean())) < 5e-3   # seeds 1 and 2: unrelated masks
+    out = torch.empty_like(ones)
+    assert lib().ecgvit_dropout_apply(ptr(ones), ptr(out), rows * d, 1.0 / 1024, 5, hip.BF16, stream()) != 0
+    A, B = torch.zeros(256, 64, device='cuda', dtype=BF16), torch.zeros(256, 64, device='cuda', dtype=BF16)
+    with pytest.raises(RuntimeError):
+        hip.gemm(hip.GEMM_NT, A, B, torch.zeros(256, 256, device='cuda', dtype=BF16), 256, 256, 64, 64, 64, 256, epilogue=hip.EPI_DROPOUT, dropout_p=1e-3, seed=1)
+
+
+@pytest.mark.parametrize('epi_extra', [0, 'lin'])
+def test_large_gemm_dropout_mask_equals_dropout_apply(epi_extra):
+    """the persistent A . B^T kernels' dropout (eight-wave body: plain + dropout; four-wave body: bias + residual + dropout, K >= 768) keeps
+    exactly the elements ecgvit_dropout_apply keeps for the same (seed, element index): one mask function for every 16-bit site"""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 2304, 768, 768
+    A, B = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    p, seed = 0.1, 77
+    C0 = torch.zeros(M, N, device='cuda', dtype=BF16)
+    C1 = torch.zeros(M, N, device='cuda', dtype=BF16)
+    bias = torch.randn(N, generator=g).cuda() if epi_extra else None
+    res = torch.zeros(M, N, device='cuda', dtype=BF16) if epi_extra else None
+    base = hip.EPI_BIAS | hip.EPI_RESIDUAL if epi_extra else 0
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C0, M, N, K, K, K, N, epilogue=base, bias=bias, residual=res, ldr=N)
+    hip.gemm(hip.GEMM_NT, dev(A), dev(B), C1, M, N, K, K, K, N, epilogue=base | hip.EPI_DROPOUT, bias=bias, residual=res, ldr=N, dropout_p=p, seed=seed)
+    C2 = torch.empty_like(C0)
+    check(lib().ecgvit_dropout_apply(ptr(C0), ptr(C2), M * N, p, seed, hip.BF16, stream()), 'dropout_apply')
+    nz = C0 != 0
+    assert torch.equal((C1 != 0) & nz, (C2 != 0) & nz)
+    assert abs(float((C1 != 0).float().mean()) - (1 - 26 / 256)) < 4e-3
+    assert rel_err(C1, C2.float()) < 4e-3
+
+
+def test_stored_gelu_within_one_bf16_ulp_of_erf():
+    """the bf16 path's GELU / GELU' (three-term erf, common.h) as STORED by the FFN-up epilogue against the f64 erf formulation evaluated on the
+    epilogue's own f32 pre-activation: within one bf16 ulp of the exact value (+ 1e-4 absolute, the approximation's floor in the negative
+    tail) over x in [-8, 8] -- the change of erf formulation (round 5) is invisible at the resolution of the stored tensors"""
+    M, N, K = 4096, 256, 64
+    A, Bm = torch.zeros(M, K), torch.zeros(N, K)
+    A[:, 0] = torch.linspace(-8, 8, M)           # rank-1 product: pre[m, n] = a[m] * 1 + bias[n], exact in f32
+    Bm[:, 0] = 1.0
+    bias = torch.linspace(-0.03, 0.03, N)
+    Ab, Bb = A.to(BF16), Bm.to(BF16)
+    pre = Ab.double()[:, :1] * Bb.double()[:, 0].unsqueeze(0) + bias.double()
+    C = torch.zeros(M, N, device='cuda', dtype=BF16)
+    aux = torch.zeros(M, N, device='cuda', dtype=BF16)
+    hip.gemm(hip.GEMM_NT, dev(Ab), dev(Bb), C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX, bias=dev(bias), aux=aux, ldaux=N)
+    pre = pre.float().double()                   # the epilogue adds the bias in f32
+    y, dy = gelu(pre), gelu_grad(pre)
+    ey = (C.double().cpu() - y).abs()
+    ed = (aux.double().cpu() - dy).abs()
+    assert bool((ey <= 2.0 ** -8 * y.abs() + 1e-4).all()), float((ey - 2.0 ** -8 * y.abs()).max())
+    assert bool((ed <= 2.0 ** -8 * dy.abs() + 1e-4).all()), float((ed - 2.0 ** -8 * dy.abs()).max())
 
 
 @pytest.mark.parametrize('B,h,N,p', [(24, 12, 251, 0.0), (45, 6, 200, 0.0), (64, 5, 130, 0.0), (40, 12, 251, 0.2), (90, 3, 256, 0.1),
