@@ -136,10 +136,18 @@ __device__ __forceinline__ uint32_t quad_keepbits(uint32_t h, uint32_t c4, bool 
     return t_hi ? (x1 & h) : (x1 | h);
 }
 __device__ __forceinline__ uint32_t quad_base(uint64_t seed, uint32_t idx) { return (idx >> 2) * ECGVIT_WEYL + seed_mix(seed); }
+// finisher of the quad form: TWO xorshift-multiply rounds ("lowbias32").  With one round (pair_finish) the top bits of a byte are not mixed enough
+// for counters that advance by d / 4 per row: at thresholds >= 128, where the keep decision rests on a byte's top two bits, single columns of a
+// [8192 x 3072] mask were kept 8 standard deviations off the rate (emulated on the host; two rounds: <= 4.2 over every shape / threshold / seed
+// tried, tests/test_gpu_ops.py::test_dropout_mask_statistics_bf16_quad_form).  Eight instructions per FOUR elements; the pair form's six per two.
+__device__ __forceinline__ uint32_t quad_finish(uint32_t h) {
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
 // returns the multiplier: 0 or 1/(1-p).  Q8: the quad form (thresh = 8-bit threshold), else the pair form (16-bit threshold)
 template <bool Q8> __device__ __forceinline__ float dropout_mult(uint64_t seed, uint32_t idx, uint32_t thresh, float inv_keep) {
     if constexpr (Q8) {
-        const uint32_t h = pair_finish(quad_base(seed, idx));
+        const uint32_t h = quad_finish(quad_base(seed, idx));
         return ((h >> (8 * (idx & 3))) & 0xFFu) >= thresh ? inv_keep : 0.f;
     } else {
         const uint32_t h = pair_hash(seed, idx);
@@ -154,7 +162,7 @@ template <int VN, bool Q8> __device__ __forceinline__ void dropout_maskN(uint64_
         const bool t_hi = thresh >= 128u;
 #pragma unroll
         for (int q = 0; q < VN / 4; ++q) {
-            const uint32_t x = quad_keepbits(pair_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
+            const uint32_t x = quad_keepbits(quad_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
 #pragma unroll
             for (int b = 0; b < 4; ++b)   // the keep bit spread over the dword (v_bfe_i32), ANDed into the multiplier's bits
                 m[4 * q + b] = __uint_as_float(ik & (uint32_t)__builtin_amdgcn_sbfe((int)x, 8 * b + 7, 1));
@@ -253,7 +261,7 @@ __device__ __forceinline__ void keepmask8(uint64_t seed, uint32_t idx0, uint32_t
     const bool t_hi = thresh >= 128u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const uint32_t x = quad_keepbits(pair_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
+        const uint32_t x = quad_keepbits(quad_finish(base + (uint32_t)q * ECGVIT_WEYL), c4, t_hi);
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const uint32_t w = __builtin_amdgcn_perm(x, x, pp ? 0x030C020Cu : 0x010C000Cu);   // bytes (2pp, 2pp + 1) -> the high bytes of the two halves

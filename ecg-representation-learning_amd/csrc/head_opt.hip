@@ -381,6 +381,6 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
 }
 
 const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi5"; }
-int ecgvit_abi_version(void) { return 5; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points
+int ecgvit_abi_version(void) { return 6; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points; 6 (round 5): ecgvit_gelu_fwd_aux, the quad dropout mask of the 16-bit sites
 
 }  // extern "C"

@@ -14,7 +14,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libecgvit_hip.so')   # the ONE library a drop-in user loads; no environment variable changes it
 
-ABI_VERSION = 5   # what ecgvit_abi_version() of a matching library returns (include/ecgvit_hip.h)
+ABI_VERSION = 6   # what ecgvit_abi_version() of a matching library returns (include/ecgvit_hip.h)
 F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
@@ -65,6 +65,7 @@ SIGNATURES = {
     'ecgvit_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'ecgvit_layernorm_bwd_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _I, _P]),
     'ecgvit_layernorm_bwd_fused_q8': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _P, _P, _P, _P]),
+    'ecgvit_gelu_fwd_aux': (c_int, [_P, _P, _L, _F, _U, _I, _P]),
     'ecgvit_dropout_apply': (c_int, [_P, _P, _L, _F, _U, _I, _P]),
     'ecgvit_colsum_workspace': (c_int64, [_L, _I]),
     'ecgvit_colsum': (c_int, [_P, _L, _P, _P, _L, _I, _I, _P]),

@@ -49,7 +49,7 @@ def test_tools_library_exports_what_its_header_declares_and_product_does_not():
 
 def test_version_and_abi():
     l = E.hip.lib()
-    assert l.ecgvit_abi_version() == 5
+    assert l.ecgvit_abi_version() == 6
     assert b'gfx950' in l.ecgvit_version()
 
 
