@@ -381,6 +381,6 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
 }
 
 const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi5"; }
-int ecgvit_abi_version(void) { return 6; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points; 6 (round 5): ecgvit_gelu_fwd_aux, the quad dropout mask of the 16-bit sites
+int ecgvit_abi_version(void) { return 6; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points; 6 (round 5): the quad dropout mask of the 16-bit sites (dropout_p of bf16 tensors is applied as round(256 p) / 256; 0 < p < 1/512 is ECGVIT_EINVAL)
 
 }  // extern "C"

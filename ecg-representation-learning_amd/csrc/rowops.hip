@@ -637,38 +637,6 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const T *__restrict_
     }
 }
 
-// FFN activation as a pass of its own (bf16; round 5): x holds the FFN-up pre-activations (bias added, as stored by the product's light epilogue);
-// in place x <- k gelu(x) keep, aux <- k gelu'(x) keep with k = 1 / (1 - p') -- what the FFN-down product and the FFN-down input gradient's
-// x-aux epilogue consume.  The same functions as the fused epilogue (gelu_fast_both_scaled, the quad mask on element index i), evaluated on the
-// ROUNDED pre-activation -- what an unfused bf16 pipeline (Linear -> GELU) computes.  Why it is a pass: fused into the product, these ~25 vector
-// instructions per element run on the two waves of a SIMD while the matrix pipe waits (20 k of a 57 k-cycle tile: profiles/r04_ffn_epilogue_candidates.txt,
-// r05_gemm_ov_experiment.txt); as a pass they run at full occupancy next to 1.2 GB of HBM traffic they overlap with.
-template <bool DROP>
-__global__ __launch_bounds__(256) void gelu_fwd_aux_kernel(bf16_t *__restrict__ x, bf16_t *__restrict__ aux, int64_t nvec, uint64_t seed, uint32_t thresh,
-                                                           float inv_keep) {
-    const float hk = ECGVIT_GELU_HK1 * inv_keep, ck = ECGVIT_GELU_CK1 * inv_keep;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(x) + i);
-        u32x4 y, dy;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float y0, y1, d0, d1;
-            gelu_fast_both_scaled(__builtin_bit_cast(float, v[k] << 16), hk, ck, y0, d0);
-            gelu_fast_both_scaled(__builtin_bit_cast(float, v[k] & 0xFFFF0000u), hk, ck, y1, d1);
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(y[k]) : "v"(y0), "v"(y1));
-            asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dy[k]) : "v"(d0), "v"(d1));
-        }
-        if constexpr (DROP) {
-            uint32_t km[4];
-            keepmask8(seed, (uint32_t)i * 8u, thresh, km);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { y[k] &= km[k]; dy[k] &= km[k]; }
-        }
-        reinterpret_cast<u32x4 *>(x)[i] = y;
-        reinterpret_cast<u32x4 *>(aux)[i] = dy;
-    }
-}
-
 inline int grid_for_rows(int64_t rows) { return (int)std::min<int64_t>((rows + 3) / 4, 2048); }
 
 }  // namespace
@@ -857,20 +825,6 @@ int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t
     else return ECGVIT_EINVAL;
     ECGVIT_CHECK_LAUNCH();
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(1024), 0, as_stream(stream), (const float *)partial, rb, N, out, out, N);
-    ECGVIT_CHECK_LAUNCH();
-    return ECGVIT_OK;
-}
-
-int ecgvit_gelu_fwd_aux(void *x, void *aux, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream) {
-    if (!x || !aux || count <= 0 || count % 8 != 0 || dtype != ECGVIT_BF16) return ECGVIT_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(aux)) % 16) return ECGVIT_EINVAL;
-    uint32_t th;
-    float ik;
-    if (!dropout_site_params(dropout_p, true, th, ik)) return ECGVIT_EINVAL;
-    const int64_t nvec = count / 8;
-    const int grid = (int)std::min<int64_t>((nvec + 255) / 256, 256 * 16);
-    if (th) hipLaunchKernelGGL(gelu_fwd_aux_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t *)x, (bf16_t *)aux, nvec, seed, th, ik);
-    else hipLaunchKernelGGL(gelu_fwd_aux_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), (bf16_t *)x, (bf16_t *)aux, nvec, seed, th, ik);
     ECGVIT_CHECK_LAUNCH();
     return ECGVIT_OK;
 }

@@ -121,9 +121,6 @@ class VitEngine:
         # 256 x 501 tokens.  Needs every reader on its 8-bit kernel: the weight-gradient kernel wants d, f % 256 == 0 and >= 4096 rows.
         # (False: keep writing them -- tests hold the two modes against each other bit for bit.)
         self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
-        # FFN activation as a pass behind the FFN-up product (bf16 operands; the 8-bit path keeps the fused, 8-bit-emitting epilogue; the f32 parity
-        # path the fused exact-erf one).  False: the fused epilogue (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX), kept for A/B and tests
-        self.split_gelu = dtype == torch.bfloat16 and not self.fp8
         self.B = None
         self._alloc_key = None
         self._pool, self._pool_group, self._pool_B = None, None, 0
@@ -494,18 +491,10 @@ class VitEngine:
                               q8_site=8 * i + 2, y8=L.get('xn2_8'))
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
-            if self.split_gelu:
-                # bf16 operands: the product stores the pre-activation (bias added) and the activation is a pass of its own -- fused, its ~25
-                # vector instructions per element hold the matrix pipe for a third of every tile (840 us per launch at base against 505 + ~240);
-                # every batch size takes this route, so a record's logits do not depend on the kernel its batch selects
-                self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, epilogue=EPI_BIAS, bias=self.P32[lp + '1.fn.net.0.bias'])
-                check(l.ecgvit_gelu_fwd_aux(ptr(L['hact']), ptr(L['hpre']), M * f, ph, s0 + 3, T, st), 'gelu_fwd_aux')
-                hq = False
-            else:
-                epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
-                hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, a8=L.get('xn2_8'), emit_site=8 * i + 3,
-                                  emit_to=L.get('hact_8'), prequant=q2, emit_only8=self._only8(M), epilogue=epi,
-                                  bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
+            epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
+            hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, a8=L.get('xn2_8'), emit_site=8 * i + 3,
+                              emit_to=L.get('hact_8'), prequant=q2, emit_only8=self._only8(M), epilogue=epi,
+                              bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
             epi = EPI_BIAS | EPI_RESIDUAL | (EPI_DROPOUT if ph > 0 else 0)
             self._linear(8 * i + 3, L['hact'], lp + '1.fn.net.3.weight', L['x2'], M, d, f, a8=L.get('hact_8'), prequant=hq, epilogue=epi,
                          bias=self.P32[lp + '1.fn.net.3.bias'], residual=L['x1'], ldr=d, dropout_p=ph, seed=s0 + 4)

@@ -65,7 +65,6 @@ SIGNATURES = {
     'ecgvit_layernorm_bwd': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'ecgvit_layernorm_bwd_fused': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _I, _P]),
     'ecgvit_layernorm_bwd_fused_q8': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _F, _U, _P, _P, _P, _P]),
-    'ecgvit_gelu_fwd_aux': (c_int, [_P, _P, _L, _F, _U, _I, _P]),
     'ecgvit_dropout_apply': (c_int, [_P, _P, _L, _F, _U, _I, _P]),
     'ecgvit_colsum_workspace': (c_int64, [_L, _I]),
     'ecgvit_colsum': (c_int, [_P, _L, _P, _P, _L, _I, _I, _P]),

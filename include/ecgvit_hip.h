@@ -194,12 +194,6 @@ int ecgvit_layernorm_bwd_fused_q8(const void *dy, const void *x, const float *ga
  * to the incoming gradient of a `dropout(acc + bias) + residual` site.  in == out allowed. */
 int ecgvit_dropout_apply(const void *in, void *out, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream);
 
-/* FFN activation as a pass of its own (bf16 only; ABI 6): in place x[i] <- k gelu(x[i]) keep(seed, i), aux[i] <- k gelu'(x[i]) keep(seed, i),
- * k = 1 / (1 - p'), over `count` (a multiple of 8) contiguous elements of the FFN-up pre-activations [M, f] (bias added): the same values
- * ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX [| ECGVIT_EPI_DROPOUT] of the product would store, evaluated on the bf16-rounded pre-activation
- * (reference: vit_pytorch FeedForward's nn.GELU() + nn.Dropout behind ecg_transformer/models/ecg_vit.py:141).  x, aux: 16-byte aligned. */
-int ecgvit_gelu_fwd_aux(void *x, void *aux, int64_t count, float dropout_p, uint64_t seed, int dtype, void *stream);
-
 /* out[n] = sum_m in[m,n]  (bias gradients).  `partial`: ecgvit_colsum_workspace(M,N) bytes. */
 int64_t ecgvit_colsum_workspace(int64_t M, int N);
 int ecgvit_colsum(const void *in, int64_t ld, float *out, void *partial, int64_t M, int N, int dtype, void *stream);
