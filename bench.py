@@ -107,7 +107,8 @@ class GemmProbe:
                 # where this count gives 0.86)
                 epi = k.get('epilogue', 0)
                 nb = (1.0 if f8 else 2.0) * (M * K + N * K) + (0.0 if C is None else 2.0) * M * N
-                nb += 2.0 * M * N * (bool(epi & probe.hip.EPI_RESIDUAL) + bool(epi & (probe.hip.EPI_GELU_GRAD_AUX | probe.hip.EPI_MUL_AUX | probe.hip.EPI_GELU_BWD | probe.hip.EPI_GELU)))
+                nb += 2.0 * M * N * bool(epi & probe.hip.EPI_RESIDUAL)
+                nb += (1.0 if epi & probe.hip.EPI_AUX8 else 2.0) * M * N * bool(epi & (probe.hip.EPI_GELU_GRAD_AUX | probe.hip.EPI_MUL_AUX | probe.hip.EPI_GELU_BWD | probe.hip.EPI_GELU))
                 nb += 1.0 * M * N * bool(epi & probe.hip.EPI_QUANT_OUT)
                 probe.bytes += nb
                 probe.n8 += 1 if f8 else 0

@@ -384,6 +384,7 @@ int ecgvit_gemm_bf16_launch(const ecgvit_gemm_desc *d, hipStream_t s, int *route
 // the one dispatch of ecgvit_gemm: executed (route == nullptr) or only asked about (route receives ECGVIT_KERNEL_*)
 static int gemm_dispatch(const ecgvit_gemm_desc *d, void *stream, int *route) {
     if (!d) return ECGVIT_EINVAL;
+    if ((d->epilogue & ECGVIT_EPI_AUX8) && !ecgvit_gemm_nt_applicable(d)) return ECGVIT_EINVAL;   // the e4m3 saved tensor exists on the large A.B^T kernel only
     if ((d->epilogue & ECGVIT_EPI_DROPOUT) && d->dropout_p > 0.f && d->out_dtype == ECGVIT_BF16 && dropout_threshold8(d->dropout_p) == 0u)
         return ECGVIT_EINVAL;   // 16-bit outputs draw 8 bits per element: 0 < p < 1/512 would silently round to no dropout
     if (d->epilogue & ECGVIT_EPI_NO_OUT) {   // no-output form: the 8-bit A . B^T kernel's emitting FFN-wide bodies only (ecgvit_gemm_nt_applicable holds the list)

@@ -142,16 +142,34 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         float dy[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) gelu_fast_both_scaled(v[k], hk, ck, v[k], dy[k]);
-        u32x4 sav, out;
+        constexpr bool kAux8 = (FL & ECGVIT_EPI_AUX8) != 0;
+        u32x4 sav = {0u, 0u, 0u, 0u}, out;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sav[k] = pack_bf16x2(dy[2 * k], dy[2 * k + 1]); out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]); }
-        if constexpr (kDrop) {
-            uint32_t km[4];
-            keepmask8(e.seed, m * (uint32_t)e.N + ncol, e.drop_thresh, km);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { sav[k] &= km[k]; out[k] &= km[k]; }
+        for (int k = 0; k < 4; ++k) {
+            if constexpr (!kAux8) sav[k] = pack_bf16x2(dy[2 * k], dy[2 * k + 1]);
+            out[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
+        [[maybe_unused]] uint32_t kmk[4] = {0u, 0u, 0u, 0u};
+        if constexpr (kDrop) {
+            keepmask8(e.seed, m * (uint32_t)e.N + ncol, e.drop_thresh, kmk);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if constexpr (!kAux8) sav[k] &= kmk[k]; out[k] &= kmk[k]; }
+        }
+        if constexpr ((FL & ECGVIT_EPI_AUX8) != 0) {
+            // the saved tensor as e4m3 bytes (from the UNROUNDED f32 values): 8 B per run -- half the stream, two crossbar moves instead of four
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(dy[0], dy[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(dy[2], dy[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(dy[4], dy[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(dy[6], dy[7], w1, true);
+            if constexpr (kDrop) {   // byte masks from the pairs' halfword masks (sav already carries them: recover from the masked bf16 pairs' keep masks)
+                w0 &= (int)__builtin_amdgcn_perm(kmk[1], kmk[0], 0x06040200u);
+                w1 &= (int)__builtin_amdgcn_perm(kmk[3], kmk[2], 0x06040200u);
+            }
+            u32x2 q;
+            q[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w0); q[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_out, w1);
+            __builtin_amdgcn_raw_buffer_store_b64(q, bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm : NT_OOB, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(nt_permute(sav, bf.t_out), bf.aux, okm ? mm * (uint32_t)bf.ldx2 + ncm * 2 : NT_OOB, 0, 0);
+        }
         if constexpr (!(FL & ECGVIT_EPI_NO_OUT))   // (NO_OUT: the consumers read the 8-bit copy only)
             __builtin_amdgcn_raw_buffer_store_b128(nt_permute(out, bf.t_out), bf.c, okm ? mm * (uint32_t)bf.ldc2 + ncm * 2 : NT_OOB, 0, CAUX);
         nt_epi8_tail<FL>(out, ok, okm, mm, ncm, bf, cs8, qmax);
@@ -189,8 +207,16 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
             for (int k = 0; k < 4; ++k) { v[2 * k] *= gelu_fast_grad(bf16_lo(auxin[k])); v[2 * k + 1] *= gelu_fast_grad(bf16_hi(auxin[k])); }
         }
         if (NT_HAS(ECGVIT_EPI_MUL_AUX)) {
+            if constexpr (FL >= 0 && (FL & ECGVIT_EPI_AUX8)) {   // e4m3 bytes: auxin[0], auxin[1] hold the run's 8 values
+                const int a0 = (int)auxin[0], a1 = (int)auxin[1];
+                v[0] *= __builtin_amdgcn_cvt_f32_fp8(a0, 0); v[1] *= __builtin_amdgcn_cvt_f32_fp8(a0, 1);
+                v[2] *= __builtin_amdgcn_cvt_f32_fp8(a0, 2); v[3] *= __builtin_amdgcn_cvt_f32_fp8(a0, 3);
+                v[4] *= __builtin_amdgcn_cvt_f32_fp8(a1, 0); v[5] *= __builtin_amdgcn_cvt_f32_fp8(a1, 1);
+                v[6] *= __builtin_amdgcn_cvt_f32_fp8(a1, 2); v[7] *= __builtin_amdgcn_cvt_f32_fp8(a1, 3);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { v[2 * k] *= bf16_lo(auxin[k]); v[2 * k + 1] *= bf16_hi(auxin[k]); }
+                for (int k = 0; k < 4; ++k) { v[2 * k] *= bf16_lo(auxin[k]); v[2 * k + 1] *= bf16_hi(auxin[k]); }
+            }
         }
         if (NT_HAS(ECGVIT_EPI_RESIDUAL)) {
 #pragma unroll
@@ -279,11 +305,25 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
     auto ld_res = [&](int i, int h) {
         return want_res ? __builtin_amdgcn_raw_buffer_load_b128(bf.res, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldr2 + (nbm + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
     };
+    constexpr bool kAux8 = FL >= 0 && (FL & ECGVIT_EPI_AUX8) != 0;
     auto ld_aux = [&](int i, int h) {
-        return want_aux ? __builtin_amdgcn_raw_buffer_load_b128(bf.aux, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldx2 + (nbm + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+        if constexpr (kAux8) {   // e4m3 bytes: 8 B per run
+            const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(bf.aux, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldx2 + (nbm + 32 * h) : NT_OOB, 0, 0);
+            return u32x4{w[0], w[1], 0u, 0u};
+        } else {
+            return want_aux ? __builtin_amdgcn_raw_buffer_load_b128(bf.aux, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldx2 + (nbm + 32 * h) * 2 : NT_OOB, 0, 0) : u32x4{};
+        }
     };
     // loaded runs arrive in the memory layout; to the accumulator layout when they are consumed
     auto to_acc = [&](const u32x4 &x, bool want) { return want ? nt_permute(x, bf.t_in) : x; };
+    auto to_acc_aux = [&](const u32x4 &x, bool want) {
+        if constexpr (kAux8) {
+            if (!want) return x;
+            return u32x4{(uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_in, (int)x[0]), (uint32_t)__builtin_amdgcn_ds_bpermute(bf.t_in, (int)x[1]), 0u, 0u};
+        } else {
+            return want ? nt_permute(x, bf.t_in) : x;
+        }
+    };
     if constexpr (kLight) {
         // light bodies: every row load of the tile is issued up front (the 64 fragment registers are free now), then the 8 row steps
         // run fully unrolled on the accumulators in place; stores are fire-and-forget
@@ -301,8 +341,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
-            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc(X[i][0], want_aux), cs, qmax);
-            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(R[i][1], want_res), to_acc(X[i][1], want_aux),
+            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc_aux(X[i][0], want_aux), cs, qmax);
+            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(R[i][1], want_res), to_acc_aux(X[i][1], want_aux),
                             cs + 8, qmax);
         }
     } else {
@@ -332,8 +372,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #undef NT_PICK
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
-            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc(a0, want_aux), cs, qmax);
-            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc(a1, want_aux), cs + 8, qmax);
+            nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc_aux(a0, want_aux), cs, qmax);
+            nt_epi8<TO, FL, CAUX>(v1, bias + 8, m, nb + 32, mok && nok1, mm, nbm + 32, mokm && nokm1, bf, e, to_acc(r1, want_res), to_acc_aux(a1, want_aux), cs + 8, qmax);
         }
     }
     if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) {   // at most one atomic max per wave and tile, only when it raises the slot (common.h: wave_amax_publish)
@@ -394,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.A), 0, (uint32_t)((int64_t)M * lda2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(d.B), 0, (uint32_t)((int64_t)N * ldb2), 0x00020000);
     NtBufs bf;
-    bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * 2;
+    bf.ldc2 = (int)d.ldc * (int)sizeof(TO); bf.ldr2 = (int)e.ldr * 2; bf.ldx2 = (int)e.ldaux * ((FL >= 0 && (FL & ECGVIT_EPI_AUX8)) ? 1 : 2);   // (AUX8: the saved tensor is bytes)
     bf.c = __builtin_amdgcn_make_buffer_rsrc(d.C, 0, ((STAMP && (ablate & 1)) || !d.C) ? 0u : (uint32_t)((int64_t)M * bf.ldc2), 0x00020000);   // ablate 1 (diagnostics): stores dropped
     bf.res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(e.residual), 0, e.residual ? (uint32_t)((int64_t)M * bf.ldr2) : 0u, 0x00020000);
     bf.aux = __builtin_amdgcn_make_buffer_rsrc(e.aux, 0, e.aux ? (uint32_t)((int64_t)M * bf.ldx2) : 0u, 0x00020000);
@@ -958,6 +998,12 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     } else if (!d->C) {
         return false;
     }
+    if (d->epilogue & ECGVIT_EPI_AUX8) {   // the e4m3 saved tensor: the two FFN-wide bodies of the bf16 kernel only
+        const int fl = d->epilogue & ~(ECGVIT_EPI_AUX8 | ECGVIT_EPI_DROPOUT);
+        const int up = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX, dh = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM;
+        if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || !d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 8) return false;
+        if (!(fl == up || d->epilogue == (dh | ECGVIT_EPI_AUX8))) return false;
+    }
     if (d->epilogue & ECGVIT_EPI_QUANT_OUT) {
         if (!f8 || !d->q8_out || !d->q8_scale || !d->q8_amax || d->ldq8 % 8 || reinterpret_cast<uintptr_t>(d->q8_out) % 8 ||
             (d->q8_format != ECGVIT_FP8_E4M3 && d->q8_format != ECGVIT_BF8_E5M2) || rows * d->ldq8 >= (1ll << 31))
@@ -1075,6 +1121,9 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_UP: NT_LAUNCH(bf16_t, F_UP); break;
             case F_UP | ECGVIT_EPI_DROPOUT: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_DROPOUT); break;
             case F_DH: NT_LAUNCH(bf16_t, F_DH); break;
+            case F_UP | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_AUX8); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8); break;
+            case F_DH | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_DH | ECGVIT_EPI_AUX8); break;
             default: NT_LAUNCH(bf16_t, -1); break;
         }
     } else {

@@ -121,6 +121,9 @@ class VitEngine:
         # 256 x 501 tokens.  Needs every reader on its 8-bit kernel: the weight-gradient kernel wants d, f % 256 == 0 and >= 4096 rows.
         # (False: keep writing them -- tests hold the two modes against each other bit for bit.)
         self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
+        # the saved FFN tensor gelu'(pre) x dropout multiplier as e4m3 bytes (ECGVIT_EPI_AUX8; bf16 operands, large A.B^T kernel): private to the
+        # FFN-up forward and the FFN-down input gradient, 790 MB per layer at base whose HBM stream costs each launch ~85 us.  False: bf16
+        self.aux8 = dtype == torch.bfloat16 and not self.fp8
         self.B = None
         self._alloc_key = None
         self._pool, self._pool_group, self._pool_B = None, None, 0
@@ -222,6 +225,12 @@ class VitEngine:
         kw.update(q8_out=out if out is not None else self.act['q8b'], ldq8=ld, q8_scale=self.f8_scale[site:site + 1], q8_amax=self.f8_amax[site:site + 1],
                   q8_format=hip.FP8_E4M3 if site % 8 < 4 else hip.BF8_E5M2)
         return True
+
+    def _aux8(self, M):
+        """the FFN-wide launches over M token rows take the large A.B^T kernel (the mirror of ecgvit_gemm_nt_applicable for [M, f] x K = d), so the
+        saved tensor may be e4m3 bytes; the library rejects the flag loudly if this ever disagrees with its own dispatch"""
+        return (self.aux8 and M >= 2048 and self.f >= 128 and self.f % 8 == 0 and self.d % 64 == 0 and self.d >= 192
+                and (M + 256) * self.f * 2 < 2 ** 31)
 
     def _only8(self, M):
         """the bf16 copies with 8-bit readers only may be left unwritten in a pass over M token rows (see `fp8_drop_dead_bf16`)"""
@@ -348,7 +357,7 @@ class VitEngine:
         sp.update(patches=((Mp, self.CP), T), tok=((Mp, d), T), x0=((M, d), T))
         for i in range(self.Ly):
             l = dict(mean1=((M,), f32), rstd1=((M,), f32), xn1=((M, d), T), qkv=((M, 3 * d), T), attn=((M, d), T), x1=((M, d), T),
-                     mean2=((M,), f32), rstd2=((M,), f32), xn2=((M, d), T), hpre=((M, f), T), hact=((M, f), T), x2=((M, d), T))
+                     mean2=((M,), f32), rstd2=((M,), f32), xn2=((M, d), T), hpre=((M, f), u8 if self._aux8(M) else T), hact=((M, f), T), x2=((M, d), T))
             if T == torch.float32:
                 l['probs'] = ((B * h * N * N,), T)
             else:
@@ -492,6 +501,8 @@ class VitEngine:
             # bf16 path: the saved tensor is gelu'(pre) * dropout multiplier (not the pre-activation): the backward of this site is then
             # one multiply in the input-gradient GEMM's epilogue -- no erf, no mask hash; the f32 parity path keeps the pre-activation
             epi = EPI_BIAS | EPI_GELU | (EPI_DROPOUT if ph > 0 else 0) | (EPI_GELU_GRAD_AUX if self.dtype == torch.bfloat16 else 0)
+            if self._aux8(M):
+                epi |= hip.EPI_AUX8
             hq = self._linear(8 * i + 2, L['xn2'], lp + '1.fn.net.0.weight', L['hact'], M, f, d, a8=L.get('xn2_8'), emit_site=8 * i + 3,
                               emit_to=L.get('hact_8'), prequant=q2, emit_only8=self._only8(M), epilogue=epi,
                               bias=self.P32[lp + '1.fn.net.0.bias'], aux=L['hpre'], ldaux=f, dropout_p=ph, seed=s0 + 3)
@@ -724,7 +735,7 @@ class VitEngine:
             self._wgrad(dY, L['hact'], lp + '1.fn.net.3.weight', d, f, M, pre=g4, x8=L.get('hact_8'), xsite=8 * i + 3)
             # dgrad with GELU' (+ dropout mask) epilogue; the epilogue also reduces the columns = gradient of the FFN-up bias
             if self.dtype == torch.bfloat16:
-                epi, pdrop = EPI_MUL_AUX | EPI_COLSUM, 0.0
+                epi, pdrop = EPI_MUL_AUX | EPI_COLSUM | (hip.EPI_AUX8 if self._aux8(M) else 0), 0.0
             else:
                 epi, pdrop = EPI_GELU_BWD | EPI_COLSUM | (EPI_DROPOUT if ph > 0 else 0), ph
             dq = self._dgrad(dY, lp + '1.fn.net.3.weight', a['dh'], M, f, d, site=8 * i + 4, emit_site=8 * i + 5, pre=g4, emit_only8=self._only8(M),

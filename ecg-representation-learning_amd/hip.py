@@ -18,7 +18,7 @@ ABI_VERSION = 6   # what ecgvit_abi_version() of a matching library returns (inc
 F32, BF16, FP8_E4M3, BF8_E5M2 = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_GELU_BWD, EPI_RESIDUAL, EPI_ACCUM, EPI_DROPOUT, EPI_COLSUM = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT, EPI_NO_OUT = 128, 256, 512, 1024
+EPI_GELU_GRAD_AUX, EPI_MUL_AUX, EPI_QUANT_OUT, EPI_NO_OUT, EPI_AUX8 = 128, 256, 512, 1024, 2048
 
 KERNEL_NONE, KERNEL_GEMM_F32, KERNEL_GEMM_BF16, KERNEL_GEMM_NT, KERNEL_GEMM_WGRAD = 0, 1, 2, 3, 4
 

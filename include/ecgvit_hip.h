@@ -73,6 +73,12 @@ int ecgvit_abi_version(void);
                                    MUL_AUX|COLSUM): C is NOT written (C may be NULL) -- q8_out, *q8_amax, aux and colsum_out are exactly what the same
                                    call without the flag produces (of the bf16-rounded values C would have held).  For a consumer chain that reads
                                    only the 8-bit copy: 128 KiB less to store per 256 x 256 tile (ABI 5)                                       */
+#define ECGVIT_EPI_AUX8 2048    /* modifies GELU_GRAD_AUX (bf16 products) and MUL_AUX: the saved tensor gelu'(v) x dropout multiplier is stored / read as e4m3 BYTES
+                                   [M, ldaux] (ldaux in bytes) instead of bf16 (ABI 6): the tensor is private to the FFN-up forward and the FFN-down input gradient,
+                                   790 MB per layer at 128 512 x 3072 whose HBM stream costs each of the two launches ~85 us (tools/gemm_ab.py --aux-ld0); values
+                                   in [-0.14, 1.13] / (1 - p): three mantissa bits, relative error <= 2^-4 per element, unbiased.  Large A.B^T kernel only
+                                   (ecgvit_gemm_kernel() == ECGVIT_KERNEL_GEMM_NT for the same descriptor), flag sets BIAS|GELU|GELU_GRAD_AUX[|DROPOUT] and
+                                   MUL_AUX|COLSUM; anything else: ECGVIT_EINVAL                                                                          */
 #define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
                                    the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
                                    max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */

@@ -915,6 +915,48 @@ def test_large_gemm_dropout_mask_equals_dropout_apply(epi_extra):
     assert rel_err(C1, C2.float()) < 4e-3
 
 
+@pytest.mark.parametrize('p', [0.0, 0.25])
+def test_ffn_saved_tensor_as_e4m3_bytes(p):
+    """ECGVIT_EPI_AUX8: the saved tensor gelu'(pre) x dropout multiplier stored by the FFN-up epilogue as e4m3 bytes and read back by the x-aux epilogue
+    of the FFN-down input gradient.  The forward OUTPUT is bit-identical with and without the flag; the bytes are the e4m3 rounding (torch's
+    float8_e4m3fn cast) of the values the bf16 form rounds to bf16 -- compared through the bf16 tensor: within 2^-4 relative + the bf16 ulp, zeros
+    (dropped elements) exactly where the bf16 form has them; the backward product with it equals the backward with the decoded bytes bit for bit
+    and stays within the format's noise of the bf16 form.  Small shapes (not on the large kernel) reject the flag."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 2304, 1024, 256
+    A, B = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    B = (B * 0.08).to(BF16)
+    bias = torch.randn(N, generator=g) * 0.3
+    Ad, Bd, bd = dev(A), dev(B), dev(bias)
+    epi = hip.EPI_BIAS | hip.EPI_GELU | hip.EPI_GELU_GRAD_AUX | (hip.EPI_DROPOUT if p > 0 else 0)
+    C1, X1 = torch.zeros(M, N, device='cuda', dtype=BF16), torch.zeros(M, N, device='cuda', dtype=BF16)
+    C2, X2 = torch.zeros(M, N, device='cuda', dtype=BF16), torch.full((M, N), 0x7F, device='cuda', dtype=torch.uint8)
+    kw = dict(bias=bd, dropout_p=p, seed=17)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C1, M, N, K, K, K, N, epilogue=epi, aux=X1, ldaux=N, **kw)
+    hip.gemm(hip.GEMM_NT, Ad, Bd, C2, M, N, K, K, K, N, epilogue=epi | hip.EPI_AUX8, aux=X2, ldaux=N, **kw)
+    assert torch.equal(C1, C2)
+    x8 = X2.view(torch.float8_e4m3fn).float()
+    x16 = X1.float()
+    assert torch.equal(x8 == 0, x16 == 0) or float(((x8 == 0) != (x16 == 0)).float().mean()) < 1e-4   # (a bf16 value below e4m3's smallest subnormal / 2 rounds to 0)
+    assert bool(((x8 - x16).abs() <= 2.0 ** -4 * x16.abs() + 2.0 ** -9).all())
+    # backward: dh = (dY . W) x aux (+ column sums)
+    dY, W = _operands(hip.GEMM_NT, M, N, K, BF16, g)
+    ws = torch.empty(8 * ((M + 255) // 256) * N, device='cuda', dtype=torch.uint8)
+    outs = []
+    for aux, extra in ((X1, 0), (X2, hip.EPI_AUX8), (x8.to(BF16), 0)):
+        D, cs = torch.zeros(M, N, device='cuda', dtype=BF16), torch.zeros(N, device='cuda')
+        hip.gemm(hip.GEMM_NT, dev(dY), dev(W), D, M, N, K, K, K, N, epilogue=hip.EPI_MUL_AUX | hip.EPI_COLSUM | extra, aux=aux, ldaux=N, workspace=ws, colsum_out=cs)
+        outs.append((D, cs))
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])      # e4m3 values are exact in bf16: same products
+    d16, d8 = outs[0][0].double().cpu().flatten(), outs[1][0].double().cpu().flatten()
+    assert float((d16 @ d8) / (d16.norm() * d8.norm())) > 0.9995
+    assert rel_err(outs[1][1], outs[0][1].double().cpu()) < 5e-3                                # column sums: the element noise averages out
+    small = torch.zeros(64, 64, device='cuda', dtype=BF16)
+    with pytest.raises(RuntimeError):
+        hip.gemm(hip.GEMM_NT, small, small, torch.zeros(64, 64, device='cuda', dtype=BF16), 64, 64, 64, 64, 64, 64, epilogue=hip.EPI_MUL_AUX | hip.EPI_AUX8,
+                 aux=torch.zeros(64, 64, device='cuda', dtype=torch.uint8), ldaux=64)
+
+
 def test_stored_gelu_within_one_bf16_ulp_of_erf():
     """the bf16 path's GELU / GELU' (three-term erf, common.h) as STORED by the FFN-up epilogue against the f64 erf formulation evaluated on the
     epilogue's own f32 pre-activation: within one bf16 ulp of the exact value (+ 1e-4 absolute, the approximation's floor in the negative

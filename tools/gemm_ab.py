@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--plain', action='store_true', help='also time every epilogue case with epilogue 0')
     ap.add_argument('--json', default='')
+    ap.add_argument('--aux-ld0', action='store_true', help='diagnostics: aux row pitch 0 (every row reads / writes ONE cache-resident row): what the aux stream costs')
     ap.add_argument('--nt4', action='store_true', help='also time the four-wave body (kernel 3) on every plain product')
     args = ap.parse_args()
     lib = hip.lib()
@@ -71,7 +72,7 @@ def main():
 
         def make(C, auxbuf):
             return hip.gemm_desc(GEMM_NT, X, W, C, M, N, K, K, K, N, epilogue=epi, bias=bias if epi & EPI_BIAS else None, residual=res,
-                                 ldr=N, aux=auxbuf, ldaux=N, dropout_p=0.1 if epi & EPI_DROPOUT else 0.0, seed=1234, workspace=ws,
+                                 ldr=N, aux=auxbuf, ldaux=0 if args.aux_ld0 else N, dropout_p=0.1 if epi & EPI_DROPOUT else 0.0, seed=1234, workspace=ws,
                                  colsum_out=cso)
 
         variants = []
