@@ -266,6 +266,7 @@ def parse_args(argv=None):
                          'per-bucket all-reduces overlapped with backward, chunked GEMM launches): what the data-parallel machinery costs without a wire')
     ap.add_argument('--grad-comm', choices=['f32', 'bf16'], default='f32', help='dtype of the gradient buckets on the wire (N > 1)')
     ap.add_argument('--hip-lib', default=None, help='measurement only: load another build of the same C-ABI (A/B candidate, tools build)')
+    ap.add_argument('--bf16-aux', action='store_true', help='measurement only (A/B): the saved FFN tensor as bf16 (round 4) instead of e4m3 bytes')
     return ap.parse_args(argv)
 
 
@@ -384,6 +385,8 @@ def main():
                               sync_nonfinite=not args.defer_nonfinite, single_rank_collectives=args.single_rank_collectives,
                               grad_comm_dtype=torch.bfloat16 if args.grad_comm == 'bf16' else torch.float32)
         run_step = step.step_masked if objective == 'masked' else step.step
+        if args.bf16_aux:
+            (model.encoder if objective == 'masked' else model)._engine().aux8 = False
         probe = None
         if not args.no_probe and dtype == torch.bfloat16:
             probe = GemmProbe(E.hip, E.hip.GEMM_NT, torch.bfloat16)

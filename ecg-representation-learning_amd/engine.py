@@ -229,8 +229,8 @@ class VitEngine:
     def _aux8(self, M):
         """the FFN-wide launches over M token rows take the large A.B^T kernel (the mirror of ecgvit_gemm_nt_applicable for [M, f] x K = d), so the
         saved tensor may be e4m3 bytes; the library rejects the flag loudly if this ever disagrees with its own dispatch"""
-        return (self.aux8 and M >= 2048 and self.f >= 128 and self.f % 8 == 0 and self.d % 64 == 0 and self.d >= 192
-                and (M + 256) * self.f * 2 < 2 ** 31)
+        return (self.aux8 and bool(self.WT) and M >= 2048 and self.f >= 128 and self.f % 8 == 0 and self.d % 64 == 0 and self.d >= 192
+                and (M + 256) * self.f * 2 < 2 ** 31)   # (self.WT: the input gradient runs as A.B^T against the transposed shadow)
 
     def _only8(self, M):
         """the bf16 copies with 8-bit readers only may be left unwritten in a pass over M token rows (see `fp8_drop_dead_bf16`)"""
@@ -321,7 +321,7 @@ class VitEngine:
         batches, or ends an epoch on a short batch, re-slices instead of freeing and re-requesting ~40 GB (base) from the allocator on
         each switch.  The pool is re-made only when a LARGER batch arrives or the objective changes (supervised <-> masked, or another
         mask count: a different token geometry)."""
-        key = (B, masked, m)
+        key = (B, masked, m, self._aux8(B * (self.n if masked else self.N)))
         if self._alloc_key == key and self.act is not None:
             return
         self._alloc_key = key

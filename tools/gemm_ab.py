@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--plain', action='store_true', help='also time every epilogue case with epilogue 0')
     ap.add_argument('--json', default='')
     ap.add_argument('--aux-ld0', action='store_true', help='diagnostics: aux row pitch 0 (every row reads / writes ONE cache-resident row): what the aux stream costs')
+    ap.add_argument('--aux8', action='store_true', help='the FFN-wide epilogues with the e4m3 saved tensor (ECGVIT_EPI_AUX8)')
     ap.add_argument('--nt4', action='store_true', help='also time the four-wave body (kernel 3) on every plain product')
     args = ap.parse_args()
     lib = hip.lib()
@@ -47,8 +48,9 @@ def main():
     tg.restype, tg.argtypes = ctypes.c_int, [ctypes.POINTER(hip.GemmDesc), ctypes.c_void_p] + [ctypes.c_int] * 3
     M, d, f = args.m, args.dim, 4 * args.dim
     LIN = EPI_BIAS | EPI_RESIDUAL | EPI_DROPOUT
-    UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT
-    DH = EPI_MUL_AUX | EPI_COLSUM
+    A8 = hip.EPI_AUX8 if args.aux8 else 0
+    UP = EPI_BIAS | EPI_GELU | EPI_GELU_GRAD_AUX | EPI_DROPOUT | A8
+    DH = EPI_MUL_AUX | EPI_COLSUM | A8
     cases = [('fwd qkv', d, 3 * d, 0), ('fwd out', d, d, LIN), ('fwd ffn_up', d, f, UP), ('fwd ffn_down', f, d, LIN),
              ('dgrad qkv', 3 * d, d, 0), ('dgrad out', d, d, 0), ('dgrad ffn_up', f, d, 0), ('dgrad ffn_down', d, f, DH)]
     if args.plain:
@@ -67,6 +69,8 @@ def main():
         bias = torch.randn(N, device=dev) * 0.1
         res = torch.randn(M, N, device=dev).to(bf) if epi & EPI_RESIDUAL else None
         aux = (torch.rand(M, N, device=dev) * 1.2).to(bf) if epi & (EPI_GELU | EPI_MUL_AUX) else None
+        if aux is not None and args.aux8:
+            aux = aux.to(torch.float8_e4m3fn).view(torch.uint8)
         cso = torch.zeros(N, device=dev) if epi & EPI_COLSUM else None
         outs = {}
 
