@@ -992,17 +992,19 @@ bool ecgvit_gemm_nt_applicable(const ecgvit_gemm_desc *d) {
     const int64_t esz = d->out_dtype == ECGVIT_BF16 ? 2 : 4, rows = (int64_t)d->M + 256;   // epilogue offsets are 32-bit byte offsets
     if (rows * d->ldc * esz >= (1ll << 31) || rows * d->ldr * 2 >= (1ll << 31) || rows * d->ldaux * 2 >= (1ll << 31)) return false;
     if (d->epilogue & ECGVIT_EPI_NO_OUT) {   // only the emitting FFN-wide bodies of the 8-bit kernel have a no-output form
-        const int fl = d->epilogue & ~(ECGVIT_EPI_NO_OUT | ECGVIT_EPI_DROPOUT);
+        const int fl = d->epilogue & ~(ECGVIT_EPI_NO_OUT | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8);
         const int up = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX | ECGVIT_EPI_QUANT_OUT, dh = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM | ECGVIT_EPI_QUANT_OUT;
-        if (!((d->dtype == ECGVIT_FP8_E4M3 && fl == up) || (d->dtype == ECGVIT_BF8_E5M2 && d->epilogue == (dh | ECGVIT_EPI_NO_OUT)))) return false;
+        if (!((d->dtype == ECGVIT_FP8_E4M3 && fl == up) || (d->dtype == ECGVIT_BF8_E5M2 && (d->epilogue & ~ECGVIT_EPI_AUX8) == (dh | ECGVIT_EPI_NO_OUT)))) return false;
     } else if (!d->C) {
         return false;
     }
-    if (d->epilogue & ECGVIT_EPI_AUX8) {   // the e4m3 saved tensor: the two FFN-wide bodies of the bf16 kernel only
-        const int fl = d->epilogue & ~(ECGVIT_EPI_AUX8 | ECGVIT_EPI_DROPOUT);
+    if (d->epilogue & ECGVIT_EPI_AUX8) {   // the e4m3 saved tensor: the two FFN-wide bodies (bf16 operands, or 8-bit operands with their emitting forms)
+        const int fl = d->epilogue & ~(ECGVIT_EPI_AUX8 | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT);
         const int up = ECGVIT_EPI_BIAS | ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_GRAD_AUX, dh = ECGVIT_EPI_MUL_AUX | ECGVIT_EPI_COLSUM;
-        if (d->dtype != ECGVIT_BF16 || d->out_dtype != ECGVIT_BF16 || !d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 8) return false;
-        if (!(fl == up || d->epilogue == (dh | ECGVIT_EPI_AUX8))) return false;
+        if (d->out_dtype != ECGVIT_BF16 || !d->aux || d->ldaux % 8 || reinterpret_cast<uintptr_t>(d->aux) % 8) return false;
+        if (d->dtype == ECGVIT_BF16 && (d->epilogue & (ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT))) return false;
+        const bool is_up = fl == up && d->dtype != ECGVIT_BF8_E5M2, is_dh = fl == dh && !(d->epilogue & ECGVIT_EPI_DROPOUT) && d->dtype != ECGVIT_FP8_E4M3;
+        if (!(is_up || is_dh)) return false;
     }
     if (d->epilogue & ECGVIT_EPI_QUANT_OUT) {
         if (!f8 || !d->q8_out || !d->q8_scale || !d->q8_amax || d->ldq8 % 8 || reinterpret_cast<uintptr_t>(d->q8_out) % 8 ||
@@ -1071,7 +1073,14 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT, 3); break;
             case F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 3); break;
             case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 3); break;
-            default: NT_LAUNCH8(-1, 3); break;
+#define A8 ECGVIT_EPI_AUX8
+            case F_UP | A8: NT_LAUNCH8(F_UP | A8, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | A8: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | A8, 3); break;
+            case F_UP | ECGVIT_EPI_QUANT_OUT | A8: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT | A8, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | A8: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | A8, 3); break;
+            case F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8: NT_LAUNCH8(F_UP | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8, 3); break;
+            case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8: NT_LAUNCH8(F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8, 3); break;
+            default: if (fl & A8) return ECGVIT_EINVAL; NT_LAUNCH8(-1, 3); break;
         }
     } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
         switch (fl) {
@@ -1079,7 +1088,11 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_DH: NT_LAUNCH8(F_DH, 4); break;
             case F_DH | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT, 4); break;
             case F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 4); break;
-            default: NT_LAUNCH8(-1, 4); break;
+            case F_DH | A8: NT_LAUNCH8(F_DH | A8, 4); break;
+            case F_DH | ECGVIT_EPI_QUANT_OUT | A8: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT | A8, 4); break;
+            case F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT | A8, 4); break;
+#undef A8
+            default: if (fl & ECGVIT_EPI_AUX8) return ECGVIT_EINVAL; NT_LAUNCH8(-1, 4); break;
         }
     } else if (d->out_dtype == ECGVIT_BF16) {
         if (fl == 0) {
@@ -1124,7 +1137,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
             case F_UP | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_AUX8); break;
             case F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8); break;
             case F_DH | ECGVIT_EPI_AUX8: NT_LAUNCH(bf16_t, F_DH | ECGVIT_EPI_AUX8); break;
-            default: NT_LAUNCH(bf16_t, -1); break;
+            default: if (fl & ECGVIT_EPI_AUX8) return ECGVIT_EINVAL; NT_LAUNCH(bf16_t, -1); break;
         }
     } else {
         if (fl == 0) NT_LAUNCH(float, 0);

@@ -121,9 +121,9 @@ class VitEngine:
         # 256 x 501 tokens.  Needs every reader on its 8-bit kernel: the weight-gradient kernel wants d, f % 256 == 0 and >= 4096 rows.
         # (False: keep writing them -- tests hold the two modes against each other bit for bit.)
         self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
-        # the saved FFN tensor gelu'(pre) x dropout multiplier as e4m3 bytes (ECGVIT_EPI_AUX8; bf16 operands, large A.B^T kernel): private to the
+        # the saved FFN tensor gelu'(pre) x dropout multiplier as e4m3 bytes (ECGVIT_EPI_AUX8; bf16 or 8-bit operands, large A.B^T kernel): private to the
         # FFN-up forward and the FFN-down input gradient, 790 MB per layer at base whose HBM stream costs each launch ~85 us.  False: bf16
-        self.aux8 = dtype == torch.bfloat16 and not self.fp8
+        self.aux8 = dtype == torch.bfloat16
         self.B = None
         self._alloc_key = None
         self._pool, self._pool_group, self._pool_B = None, None, 0

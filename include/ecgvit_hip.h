@@ -78,7 +78,7 @@ int ecgvit_abi_version(void);
                                    790 MB per layer at 128 512 x 3072 whose HBM stream costs each of the two launches ~85 us (tools/gemm_ab.py --aux-ld0); values
                                    in [-0.14, 1.13] / (1 - p): three mantissa bits, relative error <= 2^-4 per element, unbiased.  Large A.B^T kernel only
                                    (ecgvit_gemm_kernel() == ECGVIT_KERNEL_GEMM_NT for the same descriptor), flag sets BIAS|GELU|GELU_GRAD_AUX[|DROPOUT] and
-                                   MUL_AUX|COLSUM; anything else: ECGVIT_EINVAL                                                                          */
+                                   MUL_AUX|COLSUM (8-bit operands: also with QUANT_OUT [|NO_OUT]); anything else: ECGVIT_EINVAL                                                                          */
 #define ECGVIT_EPI_COLSUM 64    /* additionally colsum_out[n] = sum_m C[m,n] (of the values as stored): the bias gradient of
                                    the Linear whose output gradient this GEMM produces. Needs `workspace` of at least
                                    max(ecgvit_colsum_workspace(M,N), 8*ceil(M/256)*N) bytes. Deterministic two-stage sum. */
