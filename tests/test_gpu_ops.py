@@ -950,7 +950,10 @@ def test_ffn_saved_tensor_as_e4m3_bytes(p):
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])      # e4m3 values are exact in bf16: same products
     d16, d8 = outs[0][0].double().cpu().flatten(), outs[1][0].double().cpu().flatten()
     assert float((d16 @ d8) / (d16.norm() * d8.norm())) > 0.9995
-    assert rel_err(outs[1][1], outs[0][1].double().cpu()) < 5e-3                                # column sums: the element noise averages out
+    # column sums (the FFN-up bias gradient): each is a sum of 2304 INCOHERENT terms here (random-sign products), so the e4m3 rounding -- zero-mean, rms
+    # 2.6 % per element -- shows at its full relative size in the sum: what every gradient built from this tensor carries (cosine 0.9997 to the bf16 form)
+    c16, c8 = outs[0][1].double().cpu(), outs[1][1].double().cpu()
+    assert rel_err(c8, c16) < 4e-2 and float((c16 @ c8) / (c16.norm() * c8.norm())) > 0.999
     small = torch.zeros(64, 64, device='cuda', dtype=BF16)
     with pytest.raises(RuntimeError):
         hip.gemm(hip.GEMM_NT, small, small, torch.zeros(64, 64, device='cuda', dtype=BF16), 64, 64, 64, 64, 64, 64, epilogue=hip.EPI_MUL_AUX | hip.EPI_AUX8,
