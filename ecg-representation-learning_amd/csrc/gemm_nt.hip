@@ -405,6 +405,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #ifdef ECGVIT_TOOLS
 // diagnostics (tools build only): per block {s_memtime, s_memrealtime} at start and end, cycles summed over main loops and epilogues
 __device__ unsigned long long g_nt_stamps[256 * 8];
+// XCD rendezvous experiment (ablate bit 16): one arrival counter per XCD (own cache line), zeroed by the launcher
+__device__ unsigned int g_nt_rdv[8 * 32];
 #define NT_STAMP_T() (STAMP ? __builtin_amdgcn_s_memtime() : 0ull)
 #else
 #define NT_STAMP_T() 0ull
@@ -581,7 +583,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
 #ifdef ECGVIT_TOOLS
     if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
+    [[maybe_unused]] unsigned int rdv_cum = 0;
+    [[maybe_unused]] int rdv_round = 0;
     for (;;) {
+#ifdef ECGVIT_TOOLS
+        if constexpr (STAMP) {
+            if (ablate & 16) {
+                // experiment: the workgroups of an XCD (blockIdx & 7) start every tile round together -- their K-tiles then
+                // march through the shared activation / weight panels in step, and a panel slice fetched by one is an L2 hit for the others
+                const int x = blockIdx.x & 7, left = nitems - rdv_round * (int)gridDim.x;   // items of this round: blocks b < left take one
+                const int nb = left >= (int)gridDim.x ? (int)gridDim.x / 8 : (left > x ? (left - x + 7) / 8 : 0);
+                rdv_cum += (unsigned int)nb;
+                if (threadIdx.x == 0) {
+                    atomicAdd(&g_nt_rdv[x * 32], 1u);
+                    int spins = 0;
+                    while (__hip_atomic_load(&g_nt_rdv[x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < rdv_cum && ++spins < 20000) __builtin_amdgcn_s_sleep(1);
+                }
+                ++rdv_round;
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+#endif
         [[maybe_unused]] const unsigned long long st_a = NT_STAMP_T();
         f32x4 acc[8][4];
 #pragma unroll
@@ -1049,7 +1071,11 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #define NT_LAUNCH(TO, FL) hipLaunchKernelGGL((gemm_nt_kernel<TO, FL>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
 #ifdef ECGVIT_TOOLS
     if ((diag & 1) && d->out_dtype == ECGVIT_BF16) {   // stamped diagnostic instantiations; diag & 2: output stores dropped
-        const int ab = (diag >> 1) & 15;   // ablate bits: 1 stores dropped, 2 no DMA after the prologue, 4 no counted waits, 8 operand cursors frozen
+        const int ab = (diag >> 1) & 31;   // ablate bits: 1 stores dropped, 2 no DMA after the prologue, 4 no counted waits, 8 operand cursors frozen, 16 XCD rendezvous per tile round
+        if (ab & 16) {
+            void *p = nullptr;
+            if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_nt_rdv)) != hipSuccess || hipMemsetAsync(p, 0, sizeof(unsigned int) * 8 * 32, s) != hipSuccess) return ECGVIT_ELAUNCH;
+        }
         if (fl == 0) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
         else if (fl == (F_UP | ECGVIT_EPI_DROPOUT)) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_UP | ECGVIT_EPI_DROPOUT, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);
         else if (fl == F_DH) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, F_DH, true>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, ab);

@@ -41,6 +41,7 @@ def main():
     ap.add_argument('--json', default='')
     ap.add_argument('--aux-ld0', action='store_true', help='diagnostics: aux row pitch 0 (every row reads / writes ONE cache-resident row): what the aux stream costs')
     ap.add_argument('--aux8', action='store_true', help='the FFN-wide epilogues with the e4m3 saved tensor (ECGVIT_EPI_AUX8)')
+    ap.add_argument('--rdv', action='store_true', help='experiment: the stamped eight-wave instantiation without / with the XCD rendezvous per tile round (plain, FFN-up, x-aux cases)')
     ap.add_argument('--nt4', action='store_true', help='also time the four-wave body (kernel 3) on every plain product')
     args = ap.parse_args()
     lib = hip.lib()
@@ -87,6 +88,9 @@ def main():
             if epi == 0:
                 variants.append((f'8w g={g} nt', 2, g, 128 | 512))   # eight-wave body, non-temporal stores
             variants.append((f'shipped g={g}', 2, g, 0))             # what the library's dispatch picks
+        if args.rdv and epi in (0, UP, DH) and not args.aux8:
+            variants.append(('8w stamped', 2, 0, 1))
+            variants.append(('8w stamped rdv', 2, 0, 33))
         if args.nt4 and epi == 0:
             variants.append(('4w', 3, 0, 0))
             variants.append(('4w nt', 3, 0, 2))
