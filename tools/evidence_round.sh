@@ -1,11 +1,11 @@
 #!/bin/bash
 # Every hash-tied piece of a round's evidence in ONE gpurun call on ONE device (tools/check_profiles.py holds them to each other):
-#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/evidence_round.sh r04'
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/evidence_round.sh r05'
 # Writes gpurun_out/evidence_<round>/: copy its files into profiles/ (same names) and add the prose headers by hand.
 # Order matters: the supervised counter pass first, its summary copied into profiles/ ON THE BOX, then the driver-style bench line -- so
 # that the line's roofline.traffic comes from the counter pass of the same sources on the same device.
 : "${GRAFT_REPO_ROOT:?run through gpurun}"
-RN=${1:-r04}
+RN=${1:-r05}
 R=$GRAFT_REPO_ROOT; cd $R
 SHA=$(python3 -c "import bench; print(bench.kernel_source_hash())") || exit 1
 E=$R/gpurun_out/evidence_$RN; rm -rf $E; mkdir -p $E
@@ -23,11 +23,12 @@ pmc large_fp8 --config large --patch 10 --dtype fp8 --batch 256
 L=$R/ecg-representation-learning_amd
 python tools/gemm_ab.py --plain --nt4 --no-old 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes.txt
 python tools/gemm_ab.py --m 64256 --dim 512 --plain --nt4 --no-old 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_small.txt
-{ python tools/attn_ab.py $L/csrc/build/libecgvit_hip_r03.so $L/libecgvit_hip.so; python tools/attn_ab.py $L/csrc/build/libecgvit_hip_r03.so $L/libecgvit_hip.so --n 501; python tools/attn_variants.py; } 2>&1 | grep -v amdgpu.ids > $E/${RN}_attn_ab.txt
-python tools/attn_q8_cost.py 2>&1 | grep -v amdgpu.ids > $E/${RN}_attn_q8_cost.txt
-bash tools/pmc_attn.sh 2>&1 | grep -v amdgpu.ids > $E/${RN}_pmc_attn.txt
+python tools/gemm_ab.py --only ffn_ --aux8 --no-old --no-lib 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_aux8.txt
+python tools/gemm_ab.py --only ffn_ --aux-ld0 --no-old --no-lib 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_auxld0.txt
+# (the attention kernels did not change this round: their round-4 tables stand; the counter pass above covers them inside the step)
 python tools/stress.py 150 2>&1 | grep -v amdgpu.ids > $E/${RN}_stress.txt
-bash tools/ab_bench.sh --hip-lib "$L/csrc/build/libecgvit_hip_r03.so $L/libecgvit_hip.so" 3 2>&1 | grep -v amdgpu.ids > $E/${RN}_step_ab.txt
+# whole-line A/B against the round-4 library (bf16 saved tensor: it does not know ECGVIT_EPI_AUX8), alternating on this device
+bash tools/ab_r04.sh 3 2>&1 | grep -v amdgpu.ids > $E/${RN}_step_ab.txt
 bash tools/steady_stats.sh base > /dev/null 2>&1; cp gpurun_out/steady_base.txt $E/${RN}_steady_base.txt
 bash tools/steady_stats.sh small --config small > /dev/null 2>&1; cp gpurun_out/steady_small.txt $E/${RN}_steady_small.txt
 bash tools/steady_stats.sh large_fp8 --config large --patch 10 --dtype fp8 --batch 256 > /dev/null 2>&1; cp gpurun_out/steady_large_fp8.txt $E/${RN}_steady_large_fp8.txt
