@@ -583,6 +583,37 @@ def test_bf16_input_gradients_via_transposed_shadows_match_plain_path():
         assert torch.equal(wt.t(), eng.W[k]) and torch.equal(eng.W[k], eng.P32[k].to(BF16)), k
 
 
+def test_activation_pool_survives_batch_size_switches():
+    """train (B = 8) / eval (B = 3) alternation and a short last batch: the activation slabs come out of ONE pool sized for the largest batch seen -- a
+    smaller batch takes prefix views of it (same storage, nothing re-requested from the allocator), results equal a fresh engine's, and only a LARGER
+    batch (or another objective) re-makes the pool"""
+    kw = dict(max_signal_length=1000, patch_size=20, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256)
+    conf, ref, m, x, y = _oracle_pair(kw, 8, BF16)
+    m.train()
+    eng = m._engine()
+    xc, yc = x.cuda(), y.cuda()
+    l8 = float(m(sample_values=xc, labels=yc).loss.detach())
+    base = {k: v.data_ptr() for k, v in eng._pool.items()}
+    p_qkv = eng.act['layers'][1]['qkv'].data_ptr()
+    m.eval()
+    with torch.no_grad():
+        lg3 = m(sample_values=xc[:3].contiguous()).logits.clone()
+    assert eng.B == 3 and eng.act['layers'][1]['qkv'].data_ptr() == p_qkv and eng.act['layers'][1]['qkv'].shape[0] == 3 * eng.N
+    assert {k: v.data_ptr() for k, v in eng._pool.items()} == base                  # nothing was re-allocated
+    m.train()
+    out = m(sample_values=xc, labels=yc)
+    out.loss.backward()
+    assert float(out.loss.detach()) == l8 and {k: v.data_ptr() for k, v in eng._pool.items()} == base
+    m2 = E.EcgVit(config=conf, compute_dtype=BF16)
+    m2.load_state_dict(ref.state_dict())
+    m2.cuda().eval()
+    with torch.no_grad():
+        assert torch.equal(m2(sample_values=xc[:3].contiguous()).logits, lg3)      # a fresh engine, sized for 3 records, computes the same bits
+    x12, y12 = O.synthetic_batch(12, length=1000, seed=5)
+    assert torch.isfinite(m(sample_values=x12.cuda(), labels=y12.cuda()).loss)
+    assert eng._pool_B == 12 and eng._pool['L1.qkv'].numel() >= 12 * eng.N * 3 * 128   # grown once, for the larger batch
+
+
 # ------------------------------------------------------------------------------------------------------ f4: record feeding
 def test_device_feeder_pinned_async_batches_and_fused_transform(tmp_path):
     """double-buffered pinned H2D feeder: every batch arrives intact and in order over two epochs while the consumer keeps the
