@@ -195,7 +195,7 @@ def test_fp8_large_layer_shape_vs_cpu_oracle():
     # the 8-bit operand copies themselves (LayerNorm forward / backward, the attention kernels, EPI_QUANT_OUT epilogues).  Same weights, same
     # batch, same oracle, same tolerances; the emitting entry points must actually have run.
     eng = m8._engine()
-    fired = {'epi_quant_out': 0, 'layernorm_fwd_q8': 0, 'layernorm_bwd_fused_q8': 0, 'attention_fwd_q8': 0, 'attention_bwd_q8': 0, 'scale_update': 0}
+    fired = {'epi_quant_out': 0, 'epi_aux8': 0, 'layernorm_fwd_q8': 0, 'layernorm_bwd_fused_q8': 0, 'attention_fwd_q8': 0, 'attention_bwd_q8': 0, 'scale_update': 0}
     first_use = {'fp8_amax': 0}
     l = hip.lib()
 
@@ -223,6 +223,8 @@ def test_fp8_large_layer_shape_vs_cpu_oracle():
     def spy2(layout, *a, **k):
         if k.get('epilogue', 0) & hip.EPI_QUANT_OUT:
             fired['epi_quant_out'] += 1
+        if k.get('epilogue', 0) & hip.EPI_AUX8:          # the saved FFN tensor as e4m3 bytes (round 5): both FFN-wide launches of both layers
+            fired['epi_aux8'] += 1
         return real(layout, *a, **k)
     hip.gemm = spy2
     try:
