@@ -915,15 +915,15 @@ def test_large_gemm_dropout_mask_equals_dropout_apply(epi_extra):
     assert rel_err(C1, C2.float()) < 4e-3
 
 
-@pytest.mark.parametrize('p', [0.0, 0.25])
-def test_ffn_saved_tensor_as_e4m3_bytes(p):
+@pytest.mark.parametrize('p,M,N', [(0.0, 2304, 1024), (0.25, 2304, 1024), (0.25, 2101, 1000)])   # the last: ragged tiles in both directions (N % 8 == 0)
+def test_ffn_saved_tensor_as_e4m3_bytes(p, M, N):
     """ECGVIT_EPI_AUX8: the saved tensor gelu'(pre) x dropout multiplier stored by the FFN-up epilogue as e4m3 bytes and read back by the x-aux epilogue
     of the FFN-down input gradient.  The forward OUTPUT is bit-identical with and without the flag; the bytes are the e4m3 rounding (torch's
     float8_e4m3fn cast) of the values the bf16 form rounds to bf16 -- compared through the bf16 tensor: within 2^-4 relative + the bf16 ulp, zeros
     (dropped elements) exactly where the bf16 form has them; the backward product with it equals the backward with the decoded bytes bit for bit
     and stays within the format's noise of the bf16 form.  Small shapes (not on the large kernel) reject the flag."""
     g = torch.Generator().manual_seed(9)
-    M, N, K = 2304, 1024, 256
+    K = 256
     A, B = _operands(hip.GEMM_NT, M, N, K, BF16, g)
     B = (B * 0.08).to(BF16)
     bias = torch.randn(N, generator=g) * 0.3
