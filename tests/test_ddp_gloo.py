@@ -126,6 +126,91 @@ def test_gradient_allreduce_equals_full_batch(tmp_path, world):
     assert abs(float(out.loss.detach()) - sum(float(r['loss']) for r in rs) / world) < 1e-6   # mean of shard means
 
 
+def _masked_named(mm):
+    """(flat-layout name, parameter) of an OracleMaskedEcgVit in the package's order: the encoder's tensors, then the `pretrain.` extras"""
+    own = [(n, p) for n, p in mm.encoder.named_parameters()]
+    return own + [('pretrain.mask_token', mm.mask_token), ('pretrain.to_pixels.weight', mm.to_pixels.weight), ('pretrain.to_pixels.bias', mm.to_pixels.bias)]
+
+
+def _worker_masked(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import ecg_representation_learning_amd as E
+    from ecg_representation_learning_amd.engine import ParamLayout
+    from oracle import vit_oracle as O
+    torch.set_num_threads(2)
+    cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
+    torch.manual_seed(4321 + rank)
+    mm = O.OracleMaskedEcgVit(O.OracleEcgVit(config=cfg)).train()
+    named = _masked_named(mm)
+    layout = ParamLayout([(n, tuple(p.shape)) for n, p in named])
+    pflat = torch.zeros(layout.total)
+    for n, p in named:
+        layout.view(pflat, n).copy_(p.data)
+        p.data = layout.view(pflat, n)
+    E.ddp.broadcast_flat_(pflat, src=0)
+    G, m = 8, 10
+    x, _ = O.synthetic_batch(G, length=400, seed=77)
+    idx = torch.stack([torch.randperm(20, generator=torch.Generator().manual_seed(100 + b))[:m] for b in range(G)]).to(torch.int32)   # the GLOBAL batch's masks
+    lo, hi = E.ddp.shard_range(G, rank, world)
+    out = mm(x[lo:hi], idx[lo:hi])
+    out.loss.backward()
+    gflat = torch.zeros(layout.total)
+    for n, p in named:
+        if p.grad is not None:      # cls_token and the classification head take no part in this objective: zero, as the HIP path writes them
+            layout.view(gflat, n).copy_(p.grad)
+    ranges = layout.buckets_in_ready_order(cfg.num_hidden_layers)
+    outs = {}
+    for tag, kw in (('overlap', dict(overlap=True)), ('single', dict(overlap=False))):
+        g2 = gflat.clone()
+        ex = E.ddp.GradExchange(ranges, **kw)
+        ex.begin(g2)
+        for name in ['head'] + [n for n, _ in ranges if n != 'head']:     # the masked backward's release order: head first (known at once)
+            ex.bucket_ready(name)
+        ex.finish()
+        outs[tag] = g2 / ex.world
+    torch.save(dict(p=pflat.clone(), loss=out.loss.detach(), g=outs, tags=[n for n, _ in ranges]), os.path.join(out_dir, f'mrank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_masked_pretrain_gradient_exchange_equals_full_batch(tmp_path):
+    """the data-parallel MASKED pre-train step (the north_star's DP loop is the pre-train step) on CPU, world 2, gloo: equal shards of records AND of
+    their mask indices, the layout with the `pretrain.` extras behind the encoder (bucket order head, layers, embed, pretrain -- every element of
+    the flat buffer in exactly one bucket), sum / world = the full-batch gradient of the mean-L1 loss"""
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_masked, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'mrank{r}.pt')) for r in range(world))
+    assert torch.equal(r0['p'], r1['p']) and r0['tags'] == ['head', 'layer1', 'layer0', 'embed', 'pretrain']
+    for tag in ('overlap', 'single'):
+        assert torch.equal(r0['g'][tag], r1['g'][tag])
+    assert torch.equal(r0['g']['overlap'], r0['g']['single'])
+    from ecg_representation_learning_amd.engine import ParamLayout
+    from oracle import vit_oracle as O
+    cfg = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64)
+    torch.manual_seed(4321)
+    mm = O.OracleMaskedEcgVit(O.OracleEcgVit(config=cfg)).train()
+    named = _masked_named(mm)
+    layout = ParamLayout([(n, tuple(p.shape)) for n, p in named])
+    cover = sorted(v for _, v in layout.buckets_in_ready_order(2))
+    assert cover[0][0] == 0 and cover[-1][1] == layout.total and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    x, _ = O.synthetic_batch(8, length=400, seed=77)
+    idx = torch.stack([torch.randperm(20, generator=torch.Generator().manual_seed(100 + b))[:10] for b in range(8)]).to(torch.int32)
+    out = mm(x, idx)
+    out.loss.backward()
+    g = torch.zeros(layout.total)
+    for n, p in named:
+        if p.grad is not None:
+            layout.view(g, n).copy_(p.grad)
+    assert float((r0['g']['overlap'] - g).norm() / g.norm()) < 1e-5
+    assert abs(float(out.loss.detach()) - 0.5 * (float(r0['loss']) + float(r1['loss']))) < 1e-6
+    for n in ('vit.mlp_head.0.weight', 'vit.mlp_head.1.weight', 'vit.cls_token'):
+        assert float(layout.view(r0['g']['overlap'], n).abs().max()) == 0.0
+
+
 def test_shard_range_contract():
     import ecg_representation_learning_amd as E
     assert [E.ddp.shard_range(4096, r, 8) for r in (0, 7)] == [(0, 512), (3584, 4096)]
