@@ -251,6 +251,28 @@ __device__ __forceinline__ void gelu_fast_both_scaled(float x, float hk, float c
     dy = fmaf(x, p, c);
 }
 
+// The same arithmetic on TWO elements per instruction (round 5): gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two f32 per lane) in the
+// four cycles of a single one, and hipcc does not form them from the scalar body (|x| as a source modifier and the literal-constant fmas have no
+// packed encoding).  Written on float pairs with the constants in registers; every element sees the very operations of gelu_fast_parts_scaled in
+// the very order (IEEE fma / mul per half), so the results are bit for bit the scalar ones -- 9.5 vector instructions per element instead of 14.
+__device__ __forceinline__ f32x2 pk_splat(float a) { return f32x2{a, a}; }
+__device__ __forceinline__ void gelu_fast_both_scaled_x2(f32x2 x, float hk, float ck, f32x2 &y, f32x2 &dy) {
+    const f32x2 den = {fmaf(fabsf(x[0]), 0.47047f * 0.70710678118654752440f, 1.0f), fmaf(fabsf(x[1]), 0.47047f * 0.70710678118654752440f, 1.0f)};
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const f32x2 u = x * pk_splat(0.84932180028801904272f);   // (the sign of u does not reach -u u)
+    const f32x2 e = -u * u;
+    const f32x2 ex = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+    f32x2 poly = __builtin_elementwise_fma(t, pk_splat(0.7478556f), pk_splat(-0.0958798f));
+    poly = __builtin_elementwise_fma(t, poly, pk_splat(0.3480242f));
+    poly = t * poly;
+    const f32x2 s1 = __builtin_elementwise_fma(-poly, ex, pk_splat(1.0f));
+    const f32x2 s = {copysignf(s1[0], x[0]), copysignf(s1[1], x[1])};
+    const f32x2 cdf = __builtin_elementwise_fma(pk_splat(hk), s, pk_splat(hk));
+    const f32x2 pdf = pk_splat(ck) * ex;
+    y = x * cdf;
+    dy = __builtin_elementwise_fma(x, pdf, cdf);
+}
+
 // KEEP masks of 8 consecutive elements (a multiple of 4) for PACKED bf16 pairs (quad form): dword k = pair (2k, 2k + 1): 0xFFFF in the half of
 // a kept element.  Per quad the keep bits (3 instructions), per pair one byte permute that puts the two keep bits at the halves' sign
 // positions and one packed arithmetic shift that spreads them: the same keep set as dropout_maskN<8, true>, applied to packed results

@@ -141,7 +141,11 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
         const float hk = ECGVIT_GELU_HK1 * kk, ck = ECGVIT_GELU_CK1 * kk;   // kk == 1: the very constants every other kernel uses
         float dy[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) gelu_fast_both_scaled(v[k], hk, ck, v[k], dy[k]);
+        for (int k = 0; k < 4; ++k) {   // two elements per vector instruction (common.h), bit for bit gelu_fast_both_scaled
+            f32x2 y2, d2;
+            gelu_fast_both_scaled_x2(f32x2{v[2 * k], v[2 * k + 1]}, hk, ck, y2, d2);
+            v[2 * k] = y2[0]; v[2 * k + 1] = y2[1]; dy[2 * k] = d2[0]; dy[2 * k + 1] = d2[1];
+        }
         constexpr bool kAux8 = (FL & ECGVIT_EPI_AUX8) != 0;
         u32x4 sav = {0u, 0u, 0u, 0u}, out;
 #pragma unroll
