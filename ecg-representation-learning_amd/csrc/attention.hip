@@ -444,6 +444,13 @@ __device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit
 // Q8 (fp8_linear; bit 0: dK / dV, bit 1: dQ): additionally dqkv8 = saturate(dqkv as stored / *q8_scale) in e5m2 (same [B*N, 3*h*dh] layout, one
 // byte per element) -- the A operand of the QKV projection's two backward products, written here instead of by a quantise pass over
 // dqkv -- and *q8_amax = max(*q8_amax, max |dqkv|).  With two key windows the first launch emits its dK / dV only (dQ is final in the second).
+// `make tools TOOLS_EXTRA=-DECGVIT_ATTN_ABL=n` (tools/attn_ablate.sh): timing diagnostics with WRONG results -- one phase of the persistent backward removed
+// per build (1: dQ product, 2: dV / dK products, 3: the vector arithmetic, 4: S / dP products, 5: dS -> LDS, 6: the slab / K stream, 7: the dQ stores)
+#if defined(ECGVIT_TOOLS) && defined(ECGVIT_ATTN_ABL)
+#define ATTN_ABL(n) (((ECGVIT_ATTN_ABL) >> (n)) & 1)   // a bit mask: bit n removes phase n
+#else
+#define ATTN_ABL(n) false
+#endif
 template <bool DROP, bool ACCUM, bool STAGGER = true, int PRIO = 1, int Q8 = 0>
 __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                             const bf16_t *__restrict__ dout, const float *__restrict__ lse,
@@ -635,8 +642,10 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 dma_k(nxt, Kimg0 + (par ^ 1) * IMG);
                 lse_n = load_lse(nxt);
             }
+            if constexpr (!ATTN_ABL(6)) {
             if (qb + 3 < nqb) dma_slab(cur, qb + 3, (sl + 3) & 3);
             else if (has_next) dma_slab(nxt, qb + 3 - nqb, (sl + 3) & 3);
+            }
             // delta of the NEXT slab (visible since the previous barrier), published by this iteration's barrier
             slab_delta((sl + 1) & 3, (jj0 + qb + 1) & 1);
         };
@@ -644,6 +653,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             const char *Qrow = slab0 + ((slot0 + qb) & 3) * SLAB, *dOrow = Qrow + 4096;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            if constexpr (ATTN_ABL(4)) { asm volatile("" : "+v"(s), "+v"(dp)); return; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {   // K fragments of this wave's 32 keys come from the image every time (4 reads): 16 VGPRs less
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Qrow, ro.ks[ks]), row_frag_c(Kimg + wave * 4096, ro.ks[ks]), s, 0, 0, 0);
@@ -657,6 +667,11 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
         // dS' = P_dropped dP - p' delta' with delta' = delta (1 - p_drop); the factor `scale` is applied to the dQ tile and the dK flush instead
         // of every element (exact for the power-of-two dh^-1/2).
         auto ph_V = [&](int qb) __attribute__((always_inline)) {
+            if constexpr (ATTN_ABL(3)) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { Pk[m] = cvt_pk_bf16(s[2 * m], s[2 * m + 1]); Dk[m] = cvt_pk_bf16(dp[2 * m], dp[2 * m + 1]); }
+                return;
+            }
             const float *delta_c = delta_s + ((jj0 + qb) & 1) * 32;
             const uint32_t qpitch = (uint32_t)((N + 3) >> 2);
             const uint32_t hstep = qpitch * ECGVIT_WEYL;
@@ -696,6 +711,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             for (int m = 0; m < 8; ++m) { Pk[m] = cvt_pk_bf16(s[2 * m], s[2 * m + 1]); Dk[m] = cvt_pk_bf16(dp[2 * m], dp[2 * m + 1]); }
         };
         auto ph_B = [&](int qb) __attribute__((always_inline)) {
+            if constexpr (ATTN_ABL(2)) { asm volatile("" : "+v"(dVt[0]), "+v"(dKt[0]) : "v"(Pk[0]), "v"(Dk[0])); return; }
             const char *Qrow = slab0 + ((slot0 + qb) & 3) * SLAB, *dOrow = Qrow + 4096;
             uint32_t qa[4], da[4];
 #pragma unroll
@@ -733,6 +749,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 #undef TRM
         };
         auto ph_W = [&](int qb) __attribute__((always_inline)) {
+            if constexpr (ATTN_ABL(5)) return;
             char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -801,6 +818,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(join_halves(T[6], T[7]), join_halves(T[4], T[5]), acc, 0, 0, 0);   \
             __builtin_amdgcn_sched_barrier(0);
             bf16x4 tA[8], tB[8];
+            if constexpr (!ATTN_ABL(1)) {
             DQR(0, tA)
             DQR(1, tB)
             DQM(tA, 8)
@@ -809,6 +827,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             DQR(3, tB)
             DQM(tA, 8)
             DQM(tB, 0)
+            }
 #undef DQR
 #undef DQM
             const int q = qb * 32 + qt * 16 + dq_i;
@@ -823,6 +842,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[r] * scale + (float)o[r]);
             }
+            if constexpr (!ATTN_ABL(7))
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rdq, (q * d3 + dhc * 16 + 4 * dq_g) * 2, 0, 0);   // rows >= N: dropped
             if constexpr ((Q8 & 2) != 0) {
                 float f[4];
@@ -855,7 +875,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
                 ph_V(qb);
                 PH_STAMP(qb, 3);
                 ph_B(qb);
-                ph_W(qb);
+                ph_W(qb);   // (W ahead of B, the trailing group's order, was measured here too: 504.4 against 503.1 us)
                 PH_STAMP(qb, 4);
                 PH_STAMP(qb, 5);
                 ph_waitbar(qb);
