@@ -58,6 +58,11 @@ put(f'{rn}_step_ab.txt',
     "shipped library, tools/ab_r04.sh 3 (bench.py --steps 10 --warmup 3 --no-cpu-baseline, the default line with its nested masked / small / fp8-large runs)\n"
     + f"kernel_source_sha16: {sha} (the shipped library's sources)",
     ab + "=> " + summ + f"\nthe driver-style line of the same call: {line['value']:.0f} records/s, {line['ms_per_step']:.2f} ms (profiles/{rn}_bench_line.json)\n" + (note + '\n' if note else ''))
+if os.path.exists(os.path.join(E, f'{rn}_attn_ab.txt')):
+    put(f'{rn}_attn_ab.txt',
+        "the fused attention kernels of round 4's library against the shipped ones, tools/attn_ab.py (one process, seven interleaved rounds, median / min us; outputs compared bit for bit): "
+        "512 records x 12 heads x 251 tokens, then 256 x 16 x 501 (two key windows); dropout 0.1.  Round 5 changed the backward's vector phase only (packed f32 forms)",
+        rd(f'{rn}_attn_ab.txt'))
 for t in ('base', 'small', 'large_fp8'):
     put(f'{rn}_steady_{t}.txt', '', rd(f'{rn}_steady_{t}.txt'))
 print('assembled', rn, 'on sources', sha)

@@ -25,7 +25,9 @@ python tools/gemm_ab.py --plain --nt4 --no-old 2>&1 | grep -v amdgpu.ids > $E/${
 python tools/gemm_ab.py --m 64256 --dim 512 --plain --nt4 --no-old 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_small.txt
 python tools/gemm_ab.py --only ffn_ --aux8 --no-old --no-lib 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_aux8.txt
 python tools/gemm_ab.py --only ffn_ --aux-ld0 --no-old --no-lib 2>&1 | grep -v amdgpu.ids > $E/${RN}_gemm_shapes_auxld0.txt
-# (the attention kernels did not change this round: their round-4 tables stand; the counter pass above covers them inside the step)
+# the attention kernels against round 4's library (same process, interleaved), at the base and the large / patch-10 geometry
+python tools/attn_ab.py $L/csrc/build/libecgvit_hip_r04.so $L/libecgvit_hip.so 2>&1 | grep -v amdgpu.ids > $E/${RN}_attn_ab.txt
+python tools/attn_ab.py $L/csrc/build/libecgvit_hip_r04.so $L/libecgvit_hip.so --n 501 --b 256 --h 16 2>&1 | grep -v amdgpu.ids >> $E/${RN}_attn_ab.txt
 python tools/stress.py 150 2>&1 | grep -v amdgpu.ids > $E/${RN}_stress.txt
 # whole-line A/B against the round-4 library (bf16 saved tensor: it does not know ECGVIT_EPI_AUX8), alternating on this device
 bash tools/ab_r04.sh 3 2>&1 | grep -v amdgpu.ids > $E/${RN}_step_ab.txt
