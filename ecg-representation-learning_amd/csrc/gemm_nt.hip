@@ -217,6 +217,8 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
                 v[2] *= __builtin_amdgcn_cvt_f32_fp8(a0, 2); v[3] *= __builtin_amdgcn_cvt_f32_fp8(a0, 3);
                 v[4] *= __builtin_amdgcn_cvt_f32_fp8(a1, 0); v[5] *= __builtin_amdgcn_cvt_f32_fp8(a1, 1);
                 v[6] *= __builtin_amdgcn_cvt_f32_fp8(a1, 2); v[7] *= __builtin_amdgcn_cvt_f32_fp8(a1, 3);
+                // (two bytes per conversion + packed multiplies, and the column sums as one select per run + packed fmas -- a third of this body's vector
+                // instructions -- were measured on top of the early row request: bit-identical, no change of the launch or the step: not kept)
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { v[2 * k] *= bf16_lo(auxin[k]); v[2 * k + 1] *= bf16_hi(auxin[k]); }
@@ -261,9 +263,24 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
 // and pieces issued behind the stores would hold the next main loop until the stores are acknowledged.
 // ROLL: run a light body through the rolled loop as well (row loads one step ahead instead of all 16 up front): the four-wave kernel's
 // x-aux body -- with 256 accumulators live, 64 registers of aux rows on top of them are spilled
+// the saved-tensor rows of one wave tile as e4m3 bytes (ECGVIT_EPI_AUX8): 16 runs x 8 B in the memory layout -- what ld_aux of nt_epilogue loads.
+// gemm_nt_kernel requests them at the START of the tile's main loop (round 5: 32 registers -- the bf16 form's 64 did not fit) instead of in front
+// of the epilogue's first row, where every tile paid their HBM round trip with the matrix pipe idle.
+__device__ __forceinline__ void nt_aux8_request(u32x2 (&x)[16], const NtBufs &bf, int N, int m0, int n0, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const uint32_t mrowm = (uint32_t)(m0 + wm * 128 + (lane >> 2));
+    const int nbm = n0 + wn * 64 + 8 * (lane & 3);
+    const bool nokm0 = nbm < N, nokm1 = nbm + 32 < N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            x[2 * i + h] = __builtin_amdgcn_raw_buffer_load_b64(bf.aux, (h ? nokm1 : nokm0) ? (mrowm + 16 * i) * (uint32_t)bf.ldx2 + (nbm + 32 * h) : NT_OOB, 0, 0);
+}
+
 template <typename TO, int FL, int CAUX = 0, bool ROLL = false, typename IssueNext>
 __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gemm_desc &d, const EpiParams &e, const NtBufs &bf, int m0, int n0,
-                                            int wave, int lane, IssueNext &&issue_next) {
+                                            int wave, int lane, IssueNext &&issue_next, const u32x2 *auxpre = nullptr) {
     const int wm = wave >> 2, wn = wave & 3;
     const int c = lane & 15, q = lane >> 4;
     const int M = d.M, N = d.N;
@@ -335,7 +352,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) { R[i][h] = ld_res(i, h); X[i][h] = ld_aux(i, h); }
+            for (int h = 0; h < 2; ++h) {
+                R[i][h] = ld_res(i, h);
+                if (auxpre) X[i][h] = u32x4{auxpre[2 * i + h][0], auxpre[2 * i + h][1], 0u, 0u};   // (requested with the tile's first K-tile: nt_aux8_request)
+                else X[i][h] = ld_aux(i, h);
+            }
         if (NT_HAS(ECGVIT_EPI_QUANT_OUT)) asm volatile("" : "+v"(amax_seen));   // (waited for here, with the row loads: not behind the pieces)
         issue_next();
 #pragma unroll
@@ -583,6 +604,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     bool pre = false;     // the coming K-tile's DMA pieces were issued ahead of the previous tile's epilogue
     // VMEM instructions the epilogue leaves in flight at least: its output stores (masked lanes still issue)
     constexpr int NST = (sizeof(TO) == 2 ? 16 : 32) + ((FL >= 0 && (FL & ECGVIT_EPI_GELU)) ? 16 : 0);
+    // the x-aux input gradient with the e4m3 saved tensor (bf16 operands: the 8-bit instantiations have no 32 registers to spare): its 16 row loads
+    // per wave tile go out ahead of the tile's first K-tile -- the youngest operations in flight at that K-tile's barrier, whose counted wait lets them
+    // pass; the second K-tile's wait covers them: two K-tiles of flight time.  The same for the residual rows of the four-wave kernel (64 registers
+    // per column half, or 32 for its first four row steps) spills in its main loop AND in its epilogue: not built in
+    constexpr bool kAuxPre = OPS == 0 && sizeof(TO) == 2 && FL >= 0 && (FL & ECGVIT_EPI_MUL_AUX) && (FL & ECGVIT_EPI_AUX8) && !(FL & (ECGVIT_EPI_GELU | ECGVIT_EPI_GELU_BWD));
+    constexpr int NAUXPRE = kAuxPre ? 16 : 0;
     [[maybe_unused]] unsigned long long st_t0 = 0, st_r0 = 0, st_main = 0, st_epi = 0, st_ntile = 0;
 #ifdef ECGVIT_TOOLS
     if constexpr (STAMP) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -616,6 +643,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+        [[maybe_unused]] u32x2 auxpre[16];
+        if constexpr (kAuxPre) nt_aux8_request(auxpre, bf, N, cm0, cn0, wave, lane);
         // the K loop exists twice, once per wave group: which group a wave belongs to never changes, and as a run-time condition it cost
         // six taken branches per K-tile
         auto kloop = [&](auto late_c) __attribute__((always_inline)) {
@@ -640,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
     do {                                                                         \
         if (STAMP && (ablate & 6)) { }                                           \
         else if (a_iss) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         \
-        else if (pre_k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST) : "memory"); \
+        else if (pre_k) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + NST + NAUXPRE) : "memory"); \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    \
         __builtin_amdgcn_sched_barrier(0);                                       \
         __builtin_amdgcn_s_barrier();                                            \
@@ -723,7 +752,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(ecgvit_gemm_desc d, Epi
             }
         };
         [[maybe_unused]] const unsigned long long st_b = NT_STAMP_T();
-        nt_epilogue<TO, FL, CAUX>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next);
+        if constexpr (kAuxPre) nt_epilogue<TO, FL, CAUX>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next, auxpre);
+        else nt_epilogue<TO, FL, CAUX>(acc, d, e, bf, cm0, cn0, wave, lane, issue_next);
         if constexpr (STAMP) { st_main += st_b - st_a; st_epi += NT_STAMP_T() - st_b; ++st_ntile; }
         if (!has_next) break;
         it = next_it;
