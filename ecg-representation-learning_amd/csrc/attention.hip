@@ -29,32 +29,25 @@ namespace {
 // SPLIT (records of more than 256 tokens, e.g. patch 10 -> 501): one workgroup per (record, head, 256-query half); the keys pass through
 // the SAME 64 KiB of images in 256-key windows (the online softmax carries m, l and O across them), so two workgroups still share a CU --
 // with all 501 keys resident (128 KiB) a CU held one workgroup, two waves per SIMD, and this VALU-bound kernel ran at 2/3 of its rate.
-template <bool DROP, bool Q8 = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
-                                                               float *__restrict__ lse, int N, int h, float scale,
-                                                               uint64_t seed, uint32_t thresh, float inv_keep,
-                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
-                                                               float *__restrict__ q8_amax = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    [[maybe_unused]] unsigned int amax_seen = 0u;
-    if constexpr (Q8) amax_seen = amax_peek(q8_amax);   // (consumed behind the last store: common.h, wave_amax_publish)
-    const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
-    char *Kimg = smem, *Vimg = smem + NK * 128;
-    const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
-    const int bh = SPLIT ? blockIdx.x / nqh : blockIdx.x, qh = SPLIT ? blockIdx.x - bh * nqh : 0;
-    const int b = bh / h, hd = bh - b * h;
-    const int d = h * 64;
-    const int64_t d3 = 3 * (int64_t)d;
-    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if constexpr (!SPLIT) {
-        // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
-        dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
-        dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
+#ifdef ECGVIT_TOOLS
+__device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit_debug_attn_stamps, tools build): per-block cycle stamps, else null
+#endif
+// `make tools TOOLS_EXTRA=-DECGVIT_ATTN_ABL=n` (tools/attn_ablate.sh): timing diagnostics with WRONG results -- one phase of the persistent backward removed
+// per build (1: dQ product, 2: dV / dK products, 3: the vector arithmetic, 4: S / dP products, 5: dS -> LDS, 6: the slab / K stream, 7: the dQ stores), and of the
+// forward (8: the softmax / dropout arithmetic, 9: the Q.K^T products, 10: the P.V products, 11: the K / V image loads, 12: the output stores)
+#if defined(ECGVIT_TOOLS) && defined(ECGVIT_ATTN_ABL)
+#define ATTN_ABL(n) (((ECGVIT_ATTN_ABL) >> (n)) & 1)   // a bit mask: bit n removes phase n
+#else
+#define ATTN_ABL(n) false
+#endif
+// One wave's share of a work item: its 32-query block against the keys resident in the images (all of N <= 256, or SPLIT's 256-key windows, which it
+// loads together with the other waves of its workgroup), then the output rows and LSE.  Shared by the two forward kernels below.
+template <bool DROP, bool Q8, bool SPLIT>
+__device__ __forceinline__ void attn_fwd_wave(const bf16_t *__restrict__ base, bf16_t *__restrict__ out, float *__restrict__ lse, char *Kimg, char *Vimg,
+                                              const bf16x8 (&qf0)[4], int N, int h, int d, int64_t d3, int nkt, int bh, int b, int hd, int qh, int wave, int lane,
+                                              float scale, uint64_t seed, uint32_t thresh, float inv_keep, uint8_t *__restrict__ out8,
+                                              const float *__restrict__ q8_scale, float *__restrict__ q8_amax, unsigned int amax_seen,
+                                              unsigned long long *fst) {
     const int lr = lane & 31, lh = lane >> 5;
     const float c = scale * 1.44269504088896340736f;
     const RowOff ro = make_row_off(lane);
@@ -66,7 +59,10 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
         const int qc = q < N ? q : N - 1;
         bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (SPLIT) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
+            else qf[ks] = qf0[ks];   // (qb == wave: the loop runs at most once)
+        }
         const uint32_t rowquad = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 3) >> 2);   // first key quad of this query's row (4 keys share one hash)
         const uint32_t smix = seed_mix(seed);
 
@@ -92,6 +88,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            if constexpr (ATTN_ABL(9)) { asm volatile("" : "+v"(s)); } else
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Kimg + ktl * 4096, ro.ks[ks]), qf[ks], s, 0, 0, 0);
@@ -102,6 +99,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                     if (key >= N) s[r] = -INFINITY;
                 }
             }
+            if constexpr (!ATTN_ABL(8)) {
             float mx = s[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
@@ -140,15 +138,19 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                     for (int k = 0; k < 4; ++k) s[4 * g + k] = ((hh >> (8 * k)) & 0xFFu) >= thresh ? s[4 * g + k] : 0.f;
                 }
             }
+            }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const bf16x8 pf = pack8(s, ss);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt) {
+                    if constexpr (ATTN_ABL(10)) { asm volatile("" : "+v"(o[dt]) : "v"(pf)); continue; }
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_c(Vimg + ktl * 4096 + ss * 2048, to.lo[dt], to.hi[dt]), pf, o[dt], 0, 0, 0);
+                }
             }
         }
         l += __shfl_xor(l, 32, 64);
+        if (fst) fst[2] = __builtin_amdgcn_s_memrealtime();
         [[maybe_unused]] float qmax = 0.f;
         // output: lane (lr, lh) holds columns dt*32 + 8*g4 + 4*lh + {0..3} of query row lr -- 8-B runs interleaved with its partner lane's (lr, lh^1).
         // One v_permlane32_swap per dword hands each lane of the pair BOTH halves of two g4 groups: 16-B stores of contiguous bytes (4 per wave and
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                         const auto sw = __builtin_amdgcn_permlane32_swap(D[0][k], D[1][k], false, false);
                         st[k] = sw[0]; st[2 + k] = sw[1];
                     }
-                    if (q < N) *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh + 8 * j) = st;
+                    if (q < N && !(ATTN_ABL(12) && st[0] != 0x12345u)) *reinterpret_cast<u32x4 *>(orow + dt * 32 + 16 * lh + 8 * j) = st;
                     if constexpr (Q8) {
                         const auto sw = __builtin_amdgcn_permlane32_swap(W8[0], W8[1], false, false);
                         w8[2 * j] = sw[0]; w8[2 * j + 1] = sw[1];
@@ -208,10 +210,67 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
             }
             if (q < N && lh == 0) lse[(int64_t)bh * N + q] = m * scale + logf(l);
         }
+        if (fst) fst[3] = __builtin_amdgcn_s_memrealtime();
         if constexpr (Q8) {
             wave_amax_publish(q8_amax, qmax, amax_seen);
         }
     }
+}
+
+template <bool DROP, bool Q8 = false, bool SPLIT = false>
+__global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
+                                                               float *__restrict__ lse, int N, int h, float scale,
+                                                               uint64_t seed, uint32_t thresh, float inv_keep,
+                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                               float *__restrict__ q8_amax = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned int amax_seen = 0u;
+    if constexpr (Q8) amax_seen = amax_peek(q8_amax);   // (consumed behind the last store: common.h, wave_amax_publish)
+    const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
+    char *Kimg = smem, *Vimg = smem + NK * 128;
+    const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
+    const int d = h * 64;
+    const int64_t d3 = 3 * (int64_t)d;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // One workgroup per work item, two per CU.  Round 5 measured where such a workgroup's 16.7 us go (tools/attn_fwd_timeline.py: 4.5 us waiting for its
+    // images, 7.0 in products and softmax, 0.8 storing, 4.3 of empty slot until the next one runs) and built both persistent forms: 2 x CUs workgroups
+    // walking the items behind one barrier each (241 against 203 us at 512 x 12 x 251: the two workgroups of a CU fall into step, load together, compute
+    // together) and ONE 16-wave workgroup per CU whose two 8-wave groups alternate by construction, one computing while the other loads (218 against 194:
+    // two waves per SIMD cannot hide the LDS / MFMA / exp latencies that four do).  The dispatcher's refill keeps the phases mixed: kept.
+    // profiles/r05_attn_ablation.txt
+    const int wi = blockIdx.x;
+    const int bh = SPLIT ? wi / nqh : wi, qh = SPLIT ? wi - bh * nqh : 0;
+    const int b = bh / h, hd = bh - b * h;
+    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
+    const int lr = lane & 31, lh = lane >> 5;
+#ifdef ECGVIT_TOOLS
+    // tools/attn_fwd_timeline.py: per workgroup {start, images landed, last product done, stores issued} on the 100-MHz clock, and the hardware id
+    unsigned long long *fst = (g_attn_stamps && threadIdx.x == 0) ? g_attn_stamps + (int64_t)blockIdx.x * 8 : nullptr;
+    if (fst) { fst[0] = __builtin_amdgcn_s_memrealtime(); fst[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#else
+    unsigned long long *const fst = nullptr;
+#endif
+    [[maybe_unused]] bf16x8 qf0[4];
+    if constexpr (!SPLIT) {
+        // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
+        if constexpr (!ATTN_ABL(11)) {
+        dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
+        dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
+        }
+        // this wave's Q fragments (N <= 256: one query block per wave) travel WITH the images (round 5): requested behind the barrier, as before, their
+        // HBM round trip stood alone in front of the first product of every workgroup
+        {
+            const int q0 = wave * 32 + lr, qc0 = q0 < N ? q0 : N - 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf0[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc0 * d3 + ks * 16 + 8 * lh);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (fst) fst[1] = __builtin_amdgcn_s_memrealtime();
+    }
+
+    attn_fwd_wave<DROP, Q8, SPLIT>(base, out, lse, Kimg, Vimg, qf0, N, h, d, d3, nkt, bh, b, hd, qh, wave, lane, scale, seed, thresh, inv_keep, out8, q8_scale, q8_amax,
+                                   amax_seen, fst);
 }
 
 // =====================================================================================================
@@ -434,9 +493,6 @@ __global__ __launch_bounds__(NKT * 64) void attn_bwd_bf16_kernel(const bf16_t *_
 //     youngest operations (the slab just issued, the previous dQ store) stay in flight;
 //   * dK / dV leave through per-wave 4-KiB patches in the dS buffers; their stores are still in flight when the next item starts.
 // Math, fragment layouts, dropout indexing and the dQ tile scheme are those of the kernel above.
-#ifdef ECGVIT_TOOLS
-__device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit_debug_attn_stamps, tools build): per-block cycle stamps, else null
-#endif
 
 // Records longer than 256 tokens (N <= 512, e.g. patch 10 -> 501) run as TWO launches, one per half of the keys: `k0` is the first key
 // of this launch's 256-key window, queries always run over all of N; the second launch adds its dQ to the first one's (ACCUM).
@@ -444,13 +500,6 @@ __device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit
 // Q8 (fp8_linear; bit 0: dK / dV, bit 1: dQ): additionally dqkv8 = saturate(dqkv as stored / *q8_scale) in e5m2 (same [B*N, 3*h*dh] layout, one
 // byte per element) -- the A operand of the QKV projection's two backward products, written here instead of by a quantise pass over
 // dqkv -- and *q8_amax = max(*q8_amax, max |dqkv|).  With two key windows the first launch emits its dK / dV only (dQ is final in the second).
-// `make tools TOOLS_EXTRA=-DECGVIT_ATTN_ABL=n` (tools/attn_ablate.sh): timing diagnostics with WRONG results -- one phase of the persistent backward removed
-// per build (1: dQ product, 2: dV / dK products, 3: the vector arithmetic, 4: S / dP products, 5: dS -> LDS, 6: the slab / K stream, 7: the dQ stores)
-#if defined(ECGVIT_TOOLS) && defined(ECGVIT_ATTN_ABL)
-#define ATTN_ABL(n) (((ECGVIT_ATTN_ABL) >> (n)) & 1)   // a bit mask: bit n removes phase n
-#else
-#define ATTN_ABL(n) false
-#endif
 template <bool DROP, bool ACCUM, bool STAGGER = true, int PRIO = 1, int Q8 = 0>
 __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__restrict__ qkv, const bf16_t *__restrict__ out,
                                                             const bf16_t *__restrict__ dout, const float *__restrict__ lse,
