@@ -915,7 +915,7 @@ def test_large_gemm_dropout_mask_equals_dropout_apply(epi_extra):
     assert rel_err(C1, C2.float()) < 4e-3
 
 
-@pytest.mark.parametrize('p,M,N', [(0.0, 2304, 1024), (0.25, 2304, 1024), (0.25, 2101, 1000)])   # the last: ragged tiles in both directions (N % 8 == 0)
+@pytest.mark.parametrize('p,M,N', [(0.0, 2304, 1024), (0.25, 2304, 1024), (0.25, 2101, 1000), (0.25, 10277, 2048)])   # third: ragged tiles in both directions (N % 8 == 0); last: 328 tiles, i.e. workgroups that walk SEVERAL tiles (the x-aux launch requests a tile's saved-tensor rows with its first K-tile: counted waits across the tile boundary)
 def test_ffn_saved_tensor_as_e4m3_bytes(p, M, N):
     """ECGVIT_EPI_AUX8: the saved tensor gelu'(pre) x dropout multiplier stored by the FFN-up epilogue as e4m3 bytes and read back by the x-aux epilogue
     of the FFN-down input gradient.  The forward OUTPUT is bit-identical with and without the flag; the bytes are the e4m3 rounding (torch's
@@ -953,7 +953,7 @@ def test_ffn_saved_tensor_as_e4m3_bytes(p, M, N):
     # column sums (the FFN-up bias gradient): each is a sum of 2304 INCOHERENT terms here (random-sign products), so the e4m3 rounding -- zero-mean, rms
     # 2.6 % per element -- shows at its full relative size in the sum: what every gradient built from this tensor carries (cosine 0.9997 to the bf16 form)
     c16, c8 = outs[0][1].double().cpu(), outs[1][1].double().cpu()
-    assert rel_err(c8, c16) < 4e-2 and float((c16 @ c8) / (c16.norm() * c8.norm())) > 0.999
+    assert rel_err(c8, c16) < (4e-2 if M < 4096 else 6e-2) and float((c16 @ c8) / (c16.norm() * c8.norm())) > 0.999
     small = torch.zeros(64, 64, device='cuda', dtype=BF16)
     with pytest.raises(RuntimeError):
         hip.gemm(hip.GEMM_NT, small, small, torch.zeros(64, 64, device='cuda', dtype=BF16), 64, 64, 64, 64, 64, 64, epilogue=hip.EPI_MUL_AUX | hip.EPI_AUX8,
