@@ -266,6 +266,7 @@ def parse_args(argv=None):
                          'per-bucket all-reduces overlapped with backward, chunked GEMM launches): what the data-parallel machinery costs without a wire')
     ap.add_argument('--grad-comm', choices=['f32', 'bf16'], default='f32', help='dtype of the gradient buckets on the wire (N > 1)')
     ap.add_argument('--hip-lib', default=None, help='measurement only: load another build of the same C-ABI (A/B candidate, tools build)')
+    ap.add_argument('--mask-on-device', action='store_true', help='measurement only (A/B): hand the masked step device-resident indices (validated with three blocking reads per step)')
     ap.add_argument('--bf16-aux', action='store_true', help='measurement only (A/B): the saved FFN tensor as bf16 (round 4) instead of e4m3 bytes')
     return ap.parse_args(argv)
 
@@ -379,7 +380,9 @@ def main():
         x, y = E.workload.synthetic_batch(batch, length=conf.max_signal_length, seed=77 + rank)
         x, y = x.to(dev), y.to(dev)
         if objective == 'masked':
-            y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank)).to(dev)   # (B, m) int32
+            y = model.random_mask_indices(batch, generator=torch.Generator().manual_seed(77 + rank))   # (B, m) int32 on the HOST, as a loop that draws its masks per step has them: validated there, copied per step
+            if args.mask_on_device:
+                y = y.to(dev)
         n_total = steps + warmup
         step = E.HipTrainStep(model, E.get_train_args(dict(train_batch_size=batch * world, num_train_epoch=1), n_train=batch * world * n_total),
                               sync_nonfinite=not args.defer_nonfinite, single_rank_collectives=args.single_rank_collectives,

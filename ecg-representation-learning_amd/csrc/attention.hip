@@ -40,14 +40,48 @@ __device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit
 #else
 #define ATTN_ABL(n) false
 #endif
-// One wave's share of a work item: its 32-query block against the keys resident in the images (all of N <= 256, or SPLIT's 256-key windows, which it
-// loads together with the other waves of its workgroup), then the output rows and LSE.  Shared by the two forward kernels below.
-template <bool DROP, bool Q8, bool SPLIT>
-__device__ __forceinline__ void attn_fwd_wave(const bf16_t *__restrict__ base, bf16_t *__restrict__ out, float *__restrict__ lse, char *Kimg, char *Vimg,
-                                              const bf16x8 (&qf0)[4], int N, int h, int d, int64_t d3, int nkt, int bh, int b, int hd, int qh, int wave, int lane,
-                                              float scale, uint64_t seed, uint32_t thresh, float inv_keep, uint8_t *__restrict__ out8,
-                                              const float *__restrict__ q8_scale, float *__restrict__ q8_amax, unsigned int amax_seen,
-                                              unsigned long long *fst) {
+template <bool DROP, bool Q8 = false, bool SPLIT = false>
+__global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
+                                                               float *__restrict__ lse, int N, int h, float scale,
+                                                               uint64_t seed, uint32_t thresh, float inv_keep,
+                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                               float *__restrict__ q8_amax = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned int amax_seen = 0u;
+    if constexpr (Q8) amax_seen = amax_peek(q8_amax);   // (consumed behind the last store: common.h, wave_amax_publish)
+    const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
+    char *Kimg = smem, *Vimg = smem + NK * 128;
+    const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
+    const int bh = SPLIT ? blockIdx.x / nqh : blockIdx.x, qh = SPLIT ? blockIdx.x - bh * nqh : 0;
+    const int b = bh / h, hd = bh - b * h;
+    const int d = h * 64;
+    const int64_t d3 = 3 * (int64_t)d;
+    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // One workgroup per work item, two per CU.  Round 5 measured where such a workgroup's 16.7 us go (tools/attn_fwd_timeline.py: 4.5 us waiting for its
+    // images, 7.0 in products and softmax, 0.8 storing, 4.3 of empty slot until the next one runs) and built both persistent forms: 2 x CUs workgroups
+    // walking the items behind one barrier each (241 against 203 us at 512 x 12 x 251: the two workgroups of a CU fall into step, load together, compute
+    // together) and ONE 16-wave workgroup per CU whose two 8-wave groups alternate by construction, one computing while the other loads (218 against 194:
+    // two waves per SIMD cannot hide the LDS / MFMA / exp latencies that four do).  The dispatcher's refill keeps the phases mixed: kept.
+    // profiles/r05_attn_ablation.txt
+#ifdef ECGVIT_TOOLS
+    // tools/attn_fwd_timeline.py: per workgroup {start, images landed, last product done, stores issued} on the 100-MHz clock, and the hardware id
+    unsigned long long *fst = (g_attn_stamps && threadIdx.x == 0) ? g_attn_stamps + (int64_t)blockIdx.x * 8 : nullptr;
+    if (fst) { fst[0] = __builtin_amdgcn_s_memrealtime(); fst[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+#else
+    unsigned long long *const fst = nullptr;
+#endif
+    if constexpr (!SPLIT) {
+        // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
+        if constexpr (!ATTN_ABL(11)) {
+        dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
+        dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (fst) fst[1] = __builtin_amdgcn_s_memrealtime();
+    }
+
     const int lr = lane & 31, lh = lane >> 5;
     const float c = scale * 1.44269504088896340736f;
     const RowOff ro = make_row_off(lane);
@@ -59,10 +93,7 @@ __device__ __forceinline__ void attn_fwd_wave(const bf16_t *__restrict__ base, b
         const int qc = q < N ? q : N - 1;
         bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (SPLIT) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
-            else qf[ks] = qf0[ks];   // (qb == wave: the loop runs at most once)
-        }
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc * d3 + ks * 16 + 8 * lh);
         const uint32_t rowquad = ((uint32_t)bh * (uint32_t)N + (uint32_t)qc) * (uint32_t)((N + 3) >> 2);   // first key quad of this query's row (4 keys share one hash)
         const uint32_t smix = seed_mix(seed);
 
@@ -215,62 +246,6 @@ __device__ __forceinline__ void attn_fwd_wave(const bf16_t *__restrict__ base, b
             wave_amax_publish(q8_amax, qmax, amax_seen);
         }
     }
-}
-
-template <bool DROP, bool Q8 = false, bool SPLIT = false>
-__global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
-                                                               float *__restrict__ lse, int N, int h, float scale,
-                                                               uint64_t seed, uint32_t thresh, float inv_keep,
-                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
-                                                               float *__restrict__ q8_amax = nullptr) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    [[maybe_unused]] unsigned int amax_seen = 0u;
-    if constexpr (Q8) amax_seen = amax_peek(q8_amax);   // (consumed behind the last store: common.h, wave_amax_publish)
-    const int nkt = (N + 31) >> 5, NK = SPLIT ? 256 : nkt * 32;
-    char *Kimg = smem, *Vimg = smem + NK * 128;
-    const int nqh = SPLIT ? (nkt + 7) >> 3 : 1;                         // 256-query halves per (record, head)
-    const int d = h * 64;
-    const int64_t d3 = 3 * (int64_t)d;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // One workgroup per work item, two per CU.  Round 5 measured where such a workgroup's 16.7 us go (tools/attn_fwd_timeline.py: 4.5 us waiting for its
-    // images, 7.0 in products and softmax, 0.8 storing, 4.3 of empty slot until the next one runs) and built both persistent forms: 2 x CUs workgroups
-    // walking the items behind one barrier each (241 against 203 us at 512 x 12 x 251: the two workgroups of a CU fall into step, load together, compute
-    // together) and ONE 16-wave workgroup per CU whose two 8-wave groups alternate by construction, one computing while the other loads (218 against 194:
-    // two waves per SIMD cannot hide the LDS / MFMA / exp latencies that four do).  The dispatcher's refill keeps the phases mixed: kept.
-    // profiles/r05_attn_ablation.txt
-    const int wi = blockIdx.x;
-    const int bh = SPLIT ? wi / nqh : wi, qh = SPLIT ? wi - bh * nqh : 0;
-    const int b = bh / h, hd = bh - b * h;
-    const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
-    const int lr = lane & 31, lh = lane >> 5;
-#ifdef ECGVIT_TOOLS
-    // tools/attn_fwd_timeline.py: per workgroup {start, images landed, last product done, stores issued} on the 100-MHz clock, and the hardware id
-    unsigned long long *fst = (g_attn_stamps && threadIdx.x == 0) ? g_attn_stamps + (int64_t)blockIdx.x * 8 : nullptr;
-    if (fst) { fst[0] = __builtin_amdgcn_s_memrealtime(); fst[4] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
-#else
-    unsigned long long *const fst = nullptr;
-#endif
-    [[maybe_unused]] bf16x8 qf0[4];
-    if constexpr (!SPLIT) {
-        // K and V images by LDS-DMA: all 64 one-KiB pieces of the item in flight at once, no VGPR round trip and no ds_write pass
-        if constexpr (!ATTN_ABL(11)) {
-        dma_image<8>(Kimg, base + d, d3, N, NK, wave, lane);
-        dma_image<8>(Vimg, base + 2 * d, d3, N, NK, wave, lane);
-        }
-        // this wave's Q fragments (N <= 256: one query block per wave) travel WITH the images (round 5): requested behind the barrier, as before, their
-        // HBM round trip stood alone in front of the first product of every workgroup
-        {
-            const int q0 = wave * 32 + lr, qc0 = q0 < N ? q0 : N - 1;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf0[ks] = *reinterpret_cast<const bf16x8 *>(base + (int64_t)qc0 * d3 + ks * 16 + 8 * lh);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (fst) fst[1] = __builtin_amdgcn_s_memrealtime();
-    }
-
-    attn_fwd_wave<DROP, Q8, SPLIT>(base, out, lse, Kimg, Vimg, qf0, N, h, d, d3, nkt, bh, b, hd, qh, wave, lane, scale, seed, thresh, inv_keep, out8, q8_scale, q8_amax,
-                                   amax_seen, fst);
 }
 
 // =====================================================================================================

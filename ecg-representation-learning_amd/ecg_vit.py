@@ -15,6 +15,7 @@ calling the model with host tensors, or without the built library, raises.
 import re
 from collections import namedtuple
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -512,6 +513,15 @@ class MaskedEcgVit(nn.Module):
             raise ValueError(f'mask_idx must be (batch={batch}, m) with 0 < m <= {self.n_patch}, got {tuple(mask_idx.shape)}')
         if mask_idx.dtype.is_floating_point or mask_idx.dtype == torch.bool:
             raise ValueError(f'mask_idx must be an integer tensor, got {mask_idx.dtype}')
+        if not mask_idx.is_cuda:
+            # host indices (what random_mask_indices hands out): checked on the host -- no device round trips, so a training loop that draws its
+            # masks per step keeps the host ahead of the device (a device tensor costs three blocking reads below)
+            a = np.sort(mask_idx.numpy().astype(np.int64, copy=False), axis=1)
+            if a[:, 0].min() < 0 or a[:, -1].max() >= self.n_patch:
+                raise ValueError(f'mask_idx entries must lie in [0, {self.n_patch})')
+            if (a[:, 1:] == a[:, :-1]).any():
+                raise ValueError('mask_idx holds a duplicate patch index inside a record')
+            return
         idx = mask_idx.to(torch.int64)
         if int(idx.min()) < 0 or int(idx.max()) >= self.n_patch:
             raise ValueError(f'mask_idx entries must lie in [0, {self.n_patch})')

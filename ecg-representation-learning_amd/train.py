@@ -171,7 +171,23 @@ class HipTrainStep:
         seed = self._dropout_seed(model)
         x = sample_values.contiguous().float()
         wrapper.check_mask_indices(mask_idx, x.shape[0])
-        idx = mask_idx.to(device=x.device, dtype=torch.int32).contiguous()
+        if mask_idx.is_cuda:
+            idx = mask_idx.to(dtype=torch.int32).contiguous()
+        else:
+            # host indices (checked on the host above) travel through a pinned staging buffer: a pageable-memory copy would block the host until
+            # the device has drained the stream, i.e. once per step.  The buffer is rewritten only after its last copy has left it (an event:
+            # normally long past -- with the deferred non-finite check the host may be a step ahead)
+            st = getattr(self, '_mask_stage', None)
+            if st is None or st[0].shape != mask_idx.shape:
+                st = (torch.empty(mask_idx.shape, dtype=torch.int32).pin_memory(), torch.empty(mask_idx.shape, dtype=torch.int32, device=x.device),
+                      torch.cuda.Event())
+                self._mask_stage = st
+            else:
+                st[2].synchronize()
+            st[0].copy_(mask_idx)
+            st[1].copy_(st[0], non_blocking=True)
+            st[2].record()
+            idx = st[1]
         pred, loss = eng.forward_masked(x, idx, training=True, seed=seed)
         model._fwd_id += 1
         tpw = self._arm_overlap(model)
