@@ -1,3 +1,6 @@
+#!/bin/bash
+# masked pre-train step A/B on ONE device: csrc/build/libecgvit_hip_prev.so (`make prev` of the baseline sources) with device-resident mask indices (the
+# path that validates them with blocking reads) against the shipped library with host-resident ones; usage (GPU box): bash tools/ab_masked.sh
 P='import sys,json
 d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][0]); print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],2), d["final_loss"])'
 for i in 1 2 3; do
