@@ -245,7 +245,12 @@ def test_masked_objective_rejects_bad_indices():
                 torch.cat([good[:, :-1], torch.full((3, 1), 50)], 1),   # 50 == n_patch: out of range
                 good[:2],                                    # wrong batch
                 good.float()):                               # not an integer tensor
-        with pytest.raises(ValueError):
-            mm(x, bad)
-        with pytest.raises(ValueError):
-            E.HipTrainStep(mm, dict(n_step=5)).step_masked(x, bad)
+        for b_ in (bad, bad.cuda()):   # host indices are checked on the host, device indices with device reductions: the same verdicts
+            with pytest.raises(ValueError):
+                mm(x, b_)
+            with pytest.raises(ValueError):
+                E.HipTrainStep(mm, dict(n_step=5)).step_masked(x, b_)
+    step = E.HipTrainStep(mm, dict(n_step=5))
+    la, _ = step.step_masked(x, good)            # host indices: pinned staging buffer
+    lb, _ = step.step_masked(x, good.cuda())     # device indices
+    assert torch.isfinite(la) and torch.isfinite(lb)

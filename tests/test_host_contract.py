@@ -195,3 +195,17 @@ def test_ptbxl_splits_multi_hot_and_feeder_order(tmp_path):
     except ImportError:
         with pytest.raises(ImportError):
             E.open_records(os.path.join(tmp_path, 'x.hdf5'))   # says how to proceed without h5py
+
+
+def test_mask_indices_checked_on_the_host():
+    """MaskedEcgVit.check_mask_indices on HOST tensors (what random_mask_indices returns) needs no device: distinct indices in [0, n_patch) per record"""
+    conf = E.EcgVitConfig(max_signal_length=1000, patch_size=20, hidden_size=64, num_hidden_layers=1, num_attention_heads=1, intermediate_size=128)
+    mm = E.MaskedEcgVit(E.EcgVit(config=conf), mask_ratio=0.5)
+    good = mm.random_mask_indices(4, generator=torch.Generator().manual_seed(0))
+    assert good.shape == (4, 25) and good.dtype == torch.int32 and not good.is_cuda
+    mm.check_mask_indices(good, 4)
+    mm.check_mask_indices(good.to(torch.int64), 4)
+    for bad in (good.clone().fill_(3), torch.cat([good[:, :-1], torch.full((4, 1), 50, dtype=torch.int32)], 1),
+                torch.cat([good[:, :-1], torch.full((4, 1), -1, dtype=torch.int32)], 1), good[:2], good.float()):
+        with pytest.raises(ValueError):
+            mm.check_mask_indices(bad, 4)
