@@ -13,9 +13,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(1234)
 bf = torch.bfloat16
 t_end = time.time() + budget
-n_nt = n_tn = n_at = bad = 0
+n_nt = n_tn = n_at = n_aux8 = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'ntlin', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
+    kind = rng.choice(['nt', 'nt', 'ntlin', 'ntaux8', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -44,6 +44,29 @@ while time.time() < t_end:
             hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, epilogue=hip.EPI_BIAS | hip.EPI_RESIDUAL, bias=bias, residual=res, ldr=N, tiles_per_workgroup=tpw)
             if not torch.equal(C, want):
                 bad += 1; print('NT-LIN MISMATCH', M, N, K, tpw, int((C != want).sum()), flush=True)
+        n_nt += 1
+    elif kind == 'ntaux8':   # the x-aux input-gradient body with the e4m3 saved tensor (its rows are requested a main loop ahead, across tile boundaries):
+        # small-integer operands and exactly representable multipliers -- outputs and column sums are exact whatever the order
+        M = rng.choice([2048, 4133, 20000, 66000]) + rng.randrange(0, 256)
+        N = rng.choice([256, 520, 768, 2048, 3072])
+        K = 64 * rng.randrange(3, 7)   # (the flag needs K >= 192)
+        A = torch.randint(-1, 2, (M, K), device='cuda').to(bf); B = torch.randint(-1, 2, (N, K), device='cuda').to(bf)
+        auxv = torch.tensor([0.0, 0.5, 1.0, 1.0, 2.0], device='cuda')[torch.randint(0, 5, (M, N), device='cuda')]
+        aux8 = auxv.to(torch.float8_e4m3fn).view(torch.uint8)
+        want = ((A.float() @ B.float().t()) * auxv).to(bf)
+        wcs = want.float().sum(0)
+        ws = torch.empty(max(lib().ecgvit_colsum_workspace(M, N), 8 * ((M + 255) // 256) * N), dtype=torch.uint8, device='cuda')
+        C = torch.empty(M, N, device='cuda', dtype=bf); cs = torch.empty(N, device='cuda')
+        for tpw in (0, 0, 2):
+            C.fill_(float('nan')); cs.fill_(float('nan'))
+            try:
+                hip.gemm(hip.GEMM_NT, A, B, C, M, N, K, K, K, N, epilogue=hip.EPI_MUL_AUX | hip.EPI_COLSUM | hip.EPI_AUX8, aux=aux8, ldaux=N, workspace=ws, colsum_out=cs,
+                         tiles_per_workgroup=tpw)
+            except RuntimeError:   # (shapes the streaming kernel does not take reject the flag: not a failure)
+                break
+            n_aux8 += 1
+            if not (torch.equal(C, want) and torch.equal(cs, wcs)):
+                bad += 1; print('NT-AUX8 MISMATCH', M, N, K, tpw, int((C != want).sum()), int((cs != wcs).sum()), flush=True)
         n_nt += 1
     elif kind == 'nt8':      # 8-bit operands (e4m3 x e4m3 / e5m2 x e4m3), small integers: exact
         M = rng.choice([2048, 4133, 20000, 66000, 128256]) + rng.randrange(0, 256)
@@ -156,5 +179,5 @@ while time.time() < t_end:
         if not (err < 3e-3) or not torch.isfinite(res[0].float()).all():
             bad += 1; print('ATTN MISMATCH vs one-item kernel', B, h, N, p, err, flush=True)
         n_at += 1
-print(f'stress done: {n_nt} A.B^T shapes, {n_tn} A^T.B shapes, {n_at} attention cases, {bad} failures', flush=True)
+print(f'stress done: {n_nt} A.B^T shapes ({n_aux8} launches of the x-aux e4m3 form among them), {n_tn} A^T.B shapes, {n_at} attention cases, {bad} failures', flush=True)
 sys.exit(1 if bad else 0)
