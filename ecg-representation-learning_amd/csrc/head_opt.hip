@@ -380,7 +380,10 @@ int ecgvit_cast_bf16_to_f32(const void *src, float *dst, int64_t count, void *st
     return ECGVIT_OK;
 }
 
-const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi5"; }
-int ecgvit_abi_version(void) { return 6; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points; 6 (round 5): the quad dropout mask of the 16-bit sites (dropout_p of bf16 tensors is applied as round(256 p) / 256; 0 < p < 1/512 is ECGVIT_EINVAL)
+#define ECGVIT_ABI 6
+#define ECGVIT_STR2(x) #x
+#define ECGVIT_STR(x) ECGVIT_STR2(x)
+const char *ecgvit_version(void) { return "ecgvit-hip gfx950 abi" ECGVIT_STR(ECGVIT_ABI); }   // one constant behind both identity calls
+int ecgvit_abi_version(void) { return ECGVIT_ABI; }   // 4 (round 4): the probe / stamp / one-item entry points left the product ABI (tools/ecgvit_hip_tools.h); 5: ECGVIT_EPI_NO_OUT, NULL y / dxm in the emitting LayerNorm entry points; 6 (round 5): the quad dropout mask of the 16-bit sites (dropout_p of bf16 tensors is applied as round(256 p) / 256; 0 < p < 1/512 is ECGVIT_EINVAL)
 
 }  // extern "C"

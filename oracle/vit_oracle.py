@@ -74,6 +74,40 @@ class _PatchRearrange(nn.Module):
 # --------------------------------------------------------------------------------------
 # third-party arithmetic, restated  (vit-pytorch 0.33.2, parity unpinned)
 # --------------------------------------------------------------------------------------
+class InjectedDropout(nn.Dropout):
+    """`nn.Dropout` (the module vit-pytorch places at all five sites: embedding, attention probabilities, `to_out`, FFN hidden,
+    FFN output -- reference `models/ecg_vit.py:113-114` sets their p) whose multiplier can be INJECTED: with `mult` set to the
+    tensor of 0 / 1/(1-p) factors another implementation drew for this site, forward is `x * mult` in train AND eval mode, so the
+    oracle reproduces that implementation's dropout realisation exactly and a p > 0 step becomes comparable number for number.
+    `mult is None` (default): plain `nn.Dropout` -- torch's own generator, as in the reference."""
+    mult = None
+
+    def forward(self, x):
+        if self.mult is None:
+            return super().forward(x)
+        assert self.mult.numel() == x.numel(), (tuple(self.mult.shape), tuple(x.shape))
+        return x * self.mult.reshape(x.shape).to(x.dtype)
+
+
+def dropout_sites(vit):
+    """the five kinds of dropout site of an `OracleViT`, in the order the forward reaches them:
+    {'emb': module, 'layers': [{'probs', 'out', 'ffn', 'down'}: module per layer]}"""
+    layers = []
+    for attn, ff in vit.transformer.layers:
+        layers.append(dict(probs=attn.fn.dropout, out=attn.fn.to_out[1], ffn=ff.fn.net[2], down=ff.fn.net[4]))
+    return dict(emb=vit.dropout, layers=layers)
+
+
+def inject_dropout(vit, masks):
+    """masks: {'emb': (B, T, d) | None, 'layers': [{'probs': (B, h, T, T), 'out': (B, T, d), 'ffn': (B, T, f), 'down': (B, T, d)}]}
+    multipliers (0 or 1/(1-p)); None entries / `masks is None` restore torch's own dropout at that site"""
+    sites = dropout_sites(vit)
+    sites['emb'].mult = None if masks is None else masks.get('emb')
+    for i, s in enumerate(sites['layers']):
+        for k, mod in s.items():
+            mod.mult = None if masks is None else masks['layers'][i].get(k)
+
+
 class _PreNorm(nn.Module):
     def __init__(self, dim, fn):
         super().__init__()
@@ -91,10 +125,10 @@ class _Attention(nn.Module):
         self.heads, self.dim_head = heads, dim_head
         self.scale = dim_head ** -0.5
         self.attend = nn.Softmax(dim=-1)  # Recorder hooks this module's output (ecg_vit.py:176)
-        self.dropout = nn.Dropout(dropout)
+        self.dropout = InjectedDropout(dropout)
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
         project_out = not (heads == 1 and dim_head == dim)
-        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), InjectedDropout(dropout)) if project_out else nn.Identity()
 
     def forward(self, x):
         b, n, _ = x.shape
@@ -111,7 +145,7 @@ class _FeedForward(nn.Module):
     def __init__(self, dim, hidden, dropout):
         super().__init__()
         self.net = nn.Sequential(
-            nn.Linear(dim, hidden), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden, dim), nn.Dropout(dropout)
+            nn.Linear(dim, hidden), nn.GELU(), InjectedDropout(dropout), nn.Linear(hidden, dim), InjectedDropout(dropout)
         )
 
     def forward(self, x):
@@ -150,7 +184,7 @@ class OracleViT(nn.Module):
         self.to_patch_embedding = nn.Sequential(_PatchRearrange(pw), nn.Linear(channels * ph * pw, dim))
         self.pos_embedding = nn.Parameter(torch.randn(1, n_patch + 1, dim))
         self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
-        self.dropout = nn.Dropout(emb_dropout)
+        self.dropout = InjectedDropout(emb_dropout)
         self.transformer = _Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
         self.pool = pool
         self.to_latent = nn.Identity()

@@ -51,6 +51,7 @@ def test_version_and_abi():
     l = E.hip.lib()
     assert l.ecgvit_abi_version() == 6
     assert b'gfx950' in l.ecgvit_version()
+    assert l.ecgvit_version().decode().endswith(f'abi{l.ecgvit_abi_version()}')   # the two identity calls agree
 
 
 def test_gemm_desc_matches_header_field_order():

@@ -45,3 +45,50 @@ def test_oracle_trunk_is_the_canonical_pre_ln_encoder():
         assert float((ff.fn.net[0].weight.grad - lay.linear1.weight.grad).abs().max()) < 1e-10
         assert float((ff.norm.weight.grad - lay.norm2.weight.grad).abs().max()) < 1e-10
     assert os.path.exists(os.path.join(ROOT, 'oracle', 'vit_oracle.py'))
+
+
+def test_injected_dropout_replays_torchs_own_realisation():
+    """`InjectedDropout` (the oracle's five dropout sites; reference models/ecg_vit.py:113-114 sets their p): un-injected it IS nn.Dropout (same
+    generator stream); with the multipliers torch itself drew at every site recorded and injected back, a second pass reproduces the first to
+    rounding (1e-6) -- loss, logits and every gradient -- in train mode, and also in eval mode (injection overrides the mode).  So the injection points are all
+    the places where the model draws a mask, in the shapes `inject_dropout` documents."""
+    from conftest import Cfg
+    from oracle import vit_oracle as O
+    conf = Cfg(max_signal_length=400, patch_size=20, hidden_size=32, num_hidden_layers=2, num_attention_heads=2, intermediate_size=64,
+               hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.2)
+    torch.manual_seed(11)
+    ref = O.OracleEcgVit(config=conf).train()
+    x, y = O.synthetic_batch(3, length=400, seed=5)
+    sites = O.dropout_sites(ref.vit)
+    flat = [('emb', sites['emb'])] + [(f'{i}.{k}', m) for i, s in enumerate(sites['layers']) for k, m in s.items()]
+    assert len(flat) == 1 + 4 * 2 and all(isinstance(m, O.InjectedDropout) for _, m in flat)
+    assert sum(isinstance(m, torch.nn.Dropout) for m in ref.modules()) == len(flat)          # no dropout module outside the five kinds of site
+    rec = {}
+    hooks = [m.register_forward_hook(lambda mod, inp, out, k=k: rec.__setitem__(k, torch.where(inp[0] != 0, out / inp[0], torch.ones_like(out)).detach()))
+             for k, m in flat]
+    torch.manual_seed(99)
+    o1 = ref(sample_values=x, labels=y)
+    o1.loss.backward()
+    g1 = [p.grad.clone() for p in ref.parameters()]
+    for h in hooks:
+        h.remove()
+    # un-injected == nn.Dropout on the same generator state
+    torch.manual_seed(99)
+    o1b = ref(sample_values=x, labels=y)
+    assert torch.equal(o1.logits, o1b.logits)
+    p_emb = float((rec['emb'] == 0).float().mean())
+    assert 0.1 < p_emb < 0.3 and abs(float(rec['0.ffn'].max()) - 1 / 0.9) < 1e-5
+    masks = dict(emb=rec['emb'], layers=[{k: rec[f'{i}.{k}'] for k in ('probs', 'out', 'ffn', 'down')} for i in range(2)])
+    assert masks['layers'][0]['probs'].shape == (3, 2, 21, 21) and masks['emb'].shape == (3, 21, 32) and masks['layers'][1]['ffn'].shape == (3, 21, 64)
+    for mode in ('train', 'eval'):
+        getattr(ref, mode)()
+        O.inject_dropout(ref.vit, masks)
+        ref.zero_grad()
+        o2 = ref(sample_values=x, labels=y)
+        o2.loss.backward()
+        assert torch.allclose(o2.logits, o1.logits, rtol=0, atol=1e-6) and abs(float(o2.loss) - float(o1.loss)) < 1e-7, mode   # (the recorded ratio out / in is the multiplier up to one rounding)
+        for a, b in zip(g1, [p.grad for p in ref.parameters()]):
+            assert torch.allclose(a, b, rtol=0, atol=1e-7), mode
+    O.inject_dropout(ref.vit, None)
+    with torch.no_grad():
+        assert not torch.equal(ref(sample_values=x).logits, o1.logits)                       # injection removed: eval mode is dropout-free again
