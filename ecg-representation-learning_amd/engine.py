@@ -77,7 +77,7 @@ class VitEngine:
     """Forward / backward of EcgVit for one activation dtype (torch.float32 = parity path, torch.bfloat16 =
     throughput path). Caller provides the flat buffers; all activations are allocated here, once per batch size."""
 
-    def __init__(self, *, C, L, P, d, h, f, Ly, K, p_hidden, p_emb, dtype, layout: ParamLayout, fp8_linear=False):
+    def __init__(self, *, C, L, P, d, h, f, Ly, K, p_hidden, p_emb, dtype, layout: ParamLayout, fp8_linear=False, saved_ffn_e4m3=None):
         assert L % P == 0, 'Image dimensions must be divisible by the patch size.'  # vit_pytorch's own assertion text
         self.C, self.L, self.P, self.d, self.h, self.f, self.Ly, self.K = C, L, P, d, h, f, Ly, K
         self.n = L // P
@@ -122,8 +122,11 @@ class VitEngine:
         # (False: keep writing them -- tests hold the two modes against each other bit for bit.)
         self.fp8_drop_dead_bf16 = self.fp8 and d % 256 == 0 and f % 256 == 0
         # the saved FFN tensor gelu'(pre) x dropout multiplier as e4m3 bytes (ECGVIT_EPI_AUX8; bf16 or 8-bit operands, large A.B^T kernel): private to the
-        # FFN-up forward and the FFN-down input gradient, 790 MB per layer at base whose HBM stream costs each launch ~85 us.  False: bf16
-        self.aux8 = dtype == torch.bfloat16
+        # FFN-up forward and the FFN-down input gradient, 790 MB per layer at base whose HBM stream costs each launch ~85 us.  False: bf16.
+        # `saved_ffn_e4m3` (EcgVit(..., saved_ffn_e4m3=)): None = on for the bf16 engine; False = keep the tensor in bf16
+        if saved_ffn_e4m3 and dtype != torch.bfloat16:
+            raise ValueError('saved_ffn_e4m3 needs the bf16 engine (the f32 parity path keeps the f32 pre-activation)')
+        self.aux8 = dtype == torch.bfloat16 if saved_ffn_e4m3 is None else bool(saved_ffn_e4m3)
         self.B = None
         self._alloc_key = None
         self._pool, self._pool_group, self._pool_B = None, None, 0
@@ -328,16 +331,32 @@ class VitEngine:
         self.T = self.n if masked else self.N   # tokens per record: no CLS row in the masked-pretrain trunk
         spec = self._act_spec(B, masked, m)
         group = (masked, m)
-        pool = self._pool if self._pool_group == group else None
-        if pool is None or any(k not in pool or pool[k].dtype != dt or pool[k].numel() < _numel(sh) for k, (sh, dt) in spec.items()):
-            # grow-only inside a group (a workspace size need not be monotone in B): no batch-size sequence makes the pool thrash
-            have = {k: v.numel() for k, v in pool.items()} if pool is not None else {}
-            self.act = self._pool = pool = None   # (drop the old slabs before asking for the new ones)
-            self._pool_group, self._pool_B = group, max(B, self._pool_B if have else 0)
-            self._pool = pool = {k: torch.empty(max(_numel(sh), have.get(k, 0)), device=self.device, dtype=dt) for k, (sh, dt) in spec.items()}
+        if self._pool_group != group:
+            self.act = self._pool = None           # another token geometry: nothing of the old pool fits
+            self._pool_group, self._pool_B = group, 0
+        pool = self._pool if self._pool is not None else {}
+        self._pool = pool
+        self._pool_B = max(B, self._pool_B)
+        # Grow-only and PER SLAB inside a group: a slab is re-requested only when this pass needs more bytes of it than the pool holds (a
+        # workspace size need not be monotone in B), and slabs the current spec does not name (the e4m3 operand copies of an fp8 model while a
+        # short batch runs on the bf16 kernels) stay in the pool for the pass that wants them again.  A slab whose ELEMENT TYPE depends on the
+        # pass -- `hpre`: e4m3 bytes over >= 2048 token rows, the activation type below that -- is pooled as bytes and viewed per pass, so a
+        # batch that crosses the boundary (a short epoch remainder) re-slices like any other
+        for k, (sh, dt) in spec.items():
+            pdt = torch.uint8 if k.endswith('.hpre') else dt
+            need = _numel(sh) * (dt.itemsize if pdt != dt else 1)
+            have = pool.get(k)
+            if have is None or have.dtype != pdt or have.numel() < need:
+                if self.act is not None:
+                    self.act = None                # views of the slab being replaced die with it
+                pool[k] = None                     # (drop the old slab before asking for the new one)
+                pool[k] = torch.empty(need, device=self.device, dtype=pdt)
         a, layers = {}, [dict() for _ in range(self.Ly)]
         for k, (sh, dt) in spec.items():
-            v = pool[k][:_numel(sh)].view(sh)
+            if pool[k].dtype != dt:                # byte slab viewed in this pass's element type
+                v = pool[k][:_numel(sh) * dt.itemsize].view(dt).view(sh)
+            else:
+                v = pool[k][:_numel(sh)].view(sh)
             if k[0] == 'L' and '.' in k:
                 i, kk = k[1:].split('.', 1)
                 layers[int(i)][kk] = v

@@ -614,6 +614,45 @@ def test_activation_pool_survives_batch_size_switches():
     assert eng._pool_B == 12 and eng._pool['L1.qkv'].numel() >= 12 * eng.N * 3 * 128   # grown once, for the larger batch
 
 
+def test_activation_pool_survives_crossing_the_e4m3_saved_tensor_boundary():
+    """a batch sequence that crosses 2048 token rows: above, the saved FFN tensor `hpre` is e4m3 BYTES (ECGVIT_EPI_AUX8), below, bf16 -- the slab is pooled
+    as bytes and viewed per pass, so the long / short / long alternation (an epoch's short last batch) re-requests NOTHING, and every pass computes what
+    a fresh engine of its own size computes"""
+    kw = dict(max_signal_length=1000, patch_size=20, hidden_size=192, num_hidden_layers=2, num_attention_heads=3, intermediate_size=384)
+    conf, ref, m, x, y = _oracle_pair(kw, 45, BF16)       # 45 x 51 = 2295 token rows
+    m.train()
+    eng = m._engine()
+    xc, yc = x.cuda(), y.cuda()
+    big = m(sample_values=xc, labels=yc)
+    big.loss.backward()
+    assert eng._aux8(45 * eng.N) and eng.act['layers'][0]['hpre'].dtype == torch.uint8
+    l45, g45 = float(big.loss.detach()), m._gflat.clone()
+    base = {k: v.data_ptr() for k, v in eng._pool.items()}
+    small = m(sample_values=xc[:8].contiguous(), labels=yc[:8].contiguous())      # 408 rows: the bf16 saved tensor, on the small kernels
+    small.loss.backward()
+    assert not eng._aux8(8 * eng.N) and eng.act['layers'][0]['hpre'].dtype == BF16 and eng.act['layers'][0]['hpre'].shape == (8 * eng.N, 384)
+    assert {k: v.data_ptr() for k, v in eng._pool.items()} == base
+    l8, g8 = float(small.loss.detach()), m._gflat.clone()
+    again = m(sample_values=xc, labels=yc)
+    again.loss.backward()
+    assert {k: v.data_ptr() for k, v in eng._pool.items()} == base and eng.act['layers'][0]['hpre'].dtype == torch.uint8
+    assert float(again.loss.detach()) == l45 and torch.equal(m._gflat, g45)
+    m2 = E.EcgVit(config=conf, compute_dtype=BF16)
+    m2.load_state_dict(ref.state_dict())
+    m2.cuda().train()
+    o2 = m2(sample_values=xc[:8].contiguous(), labels=yc[:8].contiguous())
+    o2.loss.backward()
+    assert float(o2.loss.detach()) == l8 and torch.equal(m2._gflat, g8)
+    # the constructor option (saved_ffn_e4m3=False): the same model keeps the tensor in bf16 at every size
+    m3 = E.EcgVit(config=conf, compute_dtype=BF16, saved_ffn_e4m3=False)
+    m3.load_state_dict(ref.state_dict())
+    m3.cuda().train()
+    o3 = m3(sample_values=xc, labels=yc)
+    assert m3._engine().act['layers'][0]['hpre'].dtype == BF16 and float(o3.loss.detach()) == l45      # forward values do not depend on it
+    with pytest.raises(ValueError):
+        E.EcgVit(config=conf, compute_dtype=F32, saved_ffn_e4m3=True)._engine()
+
+
 # ------------------------------------------------------------------------------------------------------ f4: record feeding
 def test_device_feeder_pinned_async_batches_and_fused_transform(tmp_path):
     """double-buffered pinned H2D feeder: every batch arrives intact and in order over two epochs while the consumer keeps the
