@@ -185,6 +185,7 @@ class VitEngine:
             self.f8_amax = torch.zeros(ns, dtype=torch.float32, device=self.device)
             self.f8_fmt = torch.tensor(([hip.FP8_E4M3] * 4 + [hip.BF8_E5M2] * 4) * self.Ly, dtype=torch.int32, device=self.device)
             self._f8_seen = set()
+            self._f8_last_training, self._f8_trained = None, False
 
     # ---------------------------------------------------------------- fp8 operand path
     def refresh_fp8_weights(self):
@@ -198,11 +199,19 @@ class VitEngine:
             check(l.ecgvit_fp8_quantize(ptr(src), ptr(dst), ptr(self.w8_table), nm, self.w8_count, hip.FP8_E4M3, ptr(self.w8_scale), None, st),
                   'fp8_quantize')
 
-    def fp8_begin_step(self):
-        """delayed scaling: the scales of this pass come from the amax the previous pass's quantise kernels accumulated"""
+    def fp8_begin_step(self, training=True):
+        """delayed scaling: the scales of this pass come from the amax the previous pass's quantise kernels accumulated.
+        One exception: a TRAINING pass that follows an EVAL pass keeps the scales of the last training pass (the eval pass's amax is discarded) --
+        eval activations carry no dropout, training tensors are rescaled by 1 / (1 - p) (the FFN hidden activation most of all), and scales are
+        amax / format-max with no headroom: scales taken from an eval pass would saturate the first training step after every evaluation."""
         if self._f8_seen:
-            check(lib().ecgvit_fp8_scale_update(ptr(self.f8_scale), ptr(self.f8_amax), self.f8_scale.numel(), ptr(self.f8_fmt), 0, stream()),
-                  'fp8_scale_update')
+            if training and self._f8_last_training is False and self._f8_trained:
+                self.f8_amax.zero_()
+            else:
+                check(lib().ecgvit_fp8_scale_update(ptr(self.f8_scale), ptr(self.f8_amax), self.f8_scale.numel(), ptr(self.f8_fmt), 0, stream()),
+                      'fp8_scale_update')
+        self._f8_last_training = bool(training)
+        self._f8_trained = self._f8_trained or bool(training)
 
     def _quant(self, site, x, count, out=None):
         """x (bf16, `count` elements) -> `out` (a layer's persistent e4m3 copy: the weight-gradient product reads it again in the
@@ -551,7 +560,7 @@ class VitEngine:
             # inference-only model otherwise keeps its first batch's scales forever and clamps larger activations silently.  No backward can be
             # waiting for the old scales: a later forward overwrites the activations that backward reads (one live graph per model -- the
             # autograd node raises on a stale backward)
-            self.fp8_begin_step()
+            self.fp8_begin_step(training)
         pre = 'vit.'
         self._patch_embed(x, B)
         # a5: cat CLS, += pos_embedding[:, :n+1], emb dropout
@@ -585,7 +594,7 @@ class VitEngine:
         pe = self.p_emb if training else 0.0
         self.saved = dict(B=B, ph=ph, pe=pe, seed=seed, masked=True, idx=idx, m=m, training=training)
         if self.fp8:
-            self.fp8_begin_step()
+            self.fp8_begin_step(training)
         self._patch_embed(x, B)
         check(l.ecgvit_mask_embed_finish(ptr(a['tok']), ptr(self.P32['pretrain.mask_token']), ptr(self.P32['vit.pos_embedding']),
                                          ptr(idx), ptr(a['x0']), ptr(a['flag']), B, n, m, d, T, st), 'mask_embed_finish')

@@ -518,3 +518,40 @@ def test_dropping_the_dead_bf16_tensors_changes_no_gradient():
         outs.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).clone()))
     assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_training_scales_survive_an_eval_pass():
+    """delayed scaling across train -> eval -> train (an evaluation between epochs): the eval pass may take its scales from the training pass
+    before it (dropout-rescaled activations: larger, safe), but the training pass AFTER it must not take its forward scales from the eval pass --
+    eval activations carry no 1 / (1 - p) rescale, scales have no headroom, and the FFN hidden activation would saturate in e4m3 for that step.
+    The engine keeps the last training pass's scales there (and discards the eval pass's amax)."""
+    from oracle import vit_oracle as O
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                          hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5)   # p = 0.5: training activations are 2 x the eval ones
+    torch.manual_seed(8)
+    m = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True).cuda().train()
+    x, y = O.synthetic_batch(12, length=5000, seed=8)
+    x, y = x.cuda(), y.cuda()
+    eng = m._engine()
+    for _ in range(2):
+        m(sample_values=x, labels=y).loss.backward()
+    m(sample_values=x, labels=y)                       # its begin_step installed the scales of the second training pass
+    train_scales = eng.f8_scale.clone()
+    hact_site = 3                                      # layer 0: e4m3 copy of the FFN hidden activation (dropout-rescaled in training)
+    m.eval()
+    with torch.no_grad():
+        m(sample_values=x)
+        m(sample_values=x)                             # second eval pass: scales now come from an eval pass
+    eval_scales = eng.f8_scale.clone()
+    assert float(eval_scales[hact_site]) < 0.8 * float(train_scales[hact_site])       # what a training pass must not inherit
+    m.train()
+    out = m(sample_values=x, labels=y)
+    after = eng.f8_scale.clone()
+    fwd_sites = [8 * i + k for i in range(2) for k in range(4)]
+    assert torch.equal(after[fwd_sites], eval_scales[fwd_sites]) is False
+    # the scales in force are the ones the last TRAINING pass left (its own amax -> the training-size range), not the eval pass's
+    assert float(after[hact_site]) > 0.8 * float(train_scales[hact_site])
+    assert torch.isfinite(out.loss)
+    out.loss.backward()
+    m(sample_values=x, labels=y)                       # train -> train: plain delayed scaling again
+    assert float(eng.f8_scale[hact_site]) > 0.8 * float(train_scales[hact_site])
