@@ -18,7 +18,10 @@ Rank 0 prints ONE JSON line.  Extra objects:
                 algorithmic FLOPs of its launches / their HIP-event time measured inside the timed region, against the
                 2.5 PFLOP/s dense bf16 peak; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes, null
                 (with the reason in `traffic_source`) when the kernel sources changed since that profile was taken.
-  masked        (N = 1, default workload) the build's masked pre-train step timed in the same process: value, ms_per_step, roofline.
+  bf16_saved_tensor  (N = 1, default workload) the SAME step with the saved FFN tensor kept in bf16 (saved_ffn_e4m3=False) instead of e4m3 bytes: the headline
+                step stores one backward-only tensor per layer narrower than the metric's dtype; this is the pure-bf16-storage figure beside it.
+  masked        (N = 1, default workload) the build's masked pre-train step timed in the same process: value, ms_per_step, model TFLOP/s at its own
+                250-token FLOP count, roofline.
   small         (N = 1, default workload) BASELINE.json configs[1]: EcgVit-small bf16, 251 tokens, 256 records: value, ms_per_step, roofline.
   fp8_large     (N = 1, default workload) BASELINE.json configs[4] on one GPU: EcgVit-large / 501 tokens with fp8 Linear operands, and the
                 same step with bf16 operands back to back on the same device (value, ms_per_step, fp8_over_bf16, roofline vs 5 PFLOP/s).
@@ -75,6 +78,11 @@ def make_config(E, name, patch, length, dropout):
     return conf, batch
 
 
+BYTES_MODEL = 2   # what `roofline.alg_bytes_per_launch` counts. 1 (rounds 1-4): both operands + the output. 2 (round 5 on): + every stream of the
+                  # epilogue (residual rows, the saved GELU' x mask tensor when one is passed, the 8-bit copy of the output).  Lines with different
+                  # models are not comparable on alg_bytes / traffic ratios (tools/check_profiles.py refuses to)
+
+
 class GemmProbe:
     """HIP-event timing of every launch of ONE kernel symbol (layout, out dtype) inside the timed region."""
 
@@ -108,7 +116,8 @@ class GemmProbe:
                 epi = k.get('epilogue', 0)
                 nb = (1.0 if f8 else 2.0) * (M * K + N * K) + (0.0 if C is None else 2.0) * M * N
                 nb += 2.0 * M * N * bool(epi & probe.hip.EPI_RESIDUAL)
-                nb += (1.0 if epi & probe.hip.EPI_AUX8 else 2.0) * M * N * bool(epi & (probe.hip.EPI_GELU_GRAD_AUX | probe.hip.EPI_MUL_AUX | probe.hip.EPI_GELU_BWD | probe.hip.EPI_GELU))
+                if k.get('aux') is not None:   # (the saved tensor streams only when the caller hands one over)
+                    nb += (1.0 if epi & probe.hip.EPI_AUX8 else 2.0) * M * N * bool(epi & (probe.hip.EPI_GELU_GRAD_AUX | probe.hip.EPI_MUL_AUX | probe.hip.EPI_GELU_BWD | probe.hip.EPI_GELU))
                 nb += 1.0 * M * N * bool(epi & probe.hip.EPI_QUANT_OUT)
                 probe.bytes += nb
                 probe.n8 += 1 if f8 else 0
@@ -215,30 +224,36 @@ def cpu_baseline(conf, seconds_budget=25.0, masked=False):
             yy = torch.stack([torch.randperm(n_patch)[:n_patch // 2] for _ in range(b)]).int()
         return xx, yy
     x1, y1 = batch_of(1)
-    # pick the thread count that runs a 1-record step fastest (torch eager does not scale to hundreds of threads)
-    best = None
-    for t in sorted({min(avail, c) for c in (16, 32, 64)}):
-        torch.set_num_threads(t)
-        tr.step(x1, y1)
-        t0 = time.perf_counter()
-        tr.step(x1, y1)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (t, dt)
-    cores, t1 = best
-    torch.set_num_threads(cores)
-    b = max(1, min(32, int(seconds_budget * 0.5 / 2 / max(t1, 1e-3))))   # two timed steps in about half the budget
+    # size the sample on a 1-record probe, then pick the thread count AT THE TIMED BATCH (torch eager does not scale to hundreds of threads, and
+    # what a 1-record step likes is not what a multi-record step likes): 16 / 32 / 64 / all available cores, one step each
+    cands = sorted({min(avail, c) for c in (16, 32, 64, avail)})
+    torch.set_num_threads(cands[min(1, len(cands) - 1)])
+    tr.step(x1, y1)
+    t0 = time.perf_counter()
+    tr.step(x1, y1)
+    t1 = time.perf_counter() - t0
+    b = max(1, min(16, int(seconds_budget / 10.0 / max(t1, 1e-3))))   # ~ len(cands) probe steps + a warm-up + >= 2 timed steps inside the budget
     x, y = batch_of(b)
     tr.step(x, y)  # warm-up at the timed shape
+    probe_s = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        tr.step(x, y)
+        probe_s[t] = time.perf_counter() - t0
+    cores = min(probe_s, key=probe_s.get)
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     n = 0
     while n < 2 or (time.perf_counter() - t0 < seconds_budget * 0.4 and n < 8):
         tr.step(x, y)
         n += 1
     dt = time.perf_counter() - t0
+    probes = ', '.join(f'{t}: {b / v:.2f} rec/s' for t, v in probe_s.items())
     return dict(value=b * n / dt, unit='records/s', cores=cores, kind='port', cpu_model=cpu_model_name(), cores_available=avail,
                 sample=f'{n} full train steps (fwd+BCE+bwd+clip+AdamW, torch eager f32) of the same model on {b} synthetic '
-                       f'12x{conf.max_signal_length} records, {cores} threads of {avail} available (fastest of 16/32/64 on a 1-record probe)',
+                       f'12x{conf.max_signal_length} records, {cores} threads of {avail} available (fastest of one {b}-record step each at threads {probes})',
+                thread_probe_records_per_s={str(t): b / v for t, v in probe_s.items()},
                 tflops=b * n * flops_rec / dt / 1e12)
 
 
@@ -258,6 +273,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-probe', action='store_true')
     ap.add_argument('--no-masked', action='store_true', help='skip the nested masked pre-train measurement')
+    ap.add_argument('--no-bf16-saved', action='store_true', help='skip the nested measurement of the same step with the saved FFN tensor in bf16')
     ap.add_argument('--no-small', action='store_true', help='skip the nested EcgVit-small measurement (BASELINE.json configs[1])')
     ap.add_argument('--no-fp8-large', action='store_true', help='skip the nested EcgVit-large fp8 / bf16 measurement (BASELINE.json configs[4] on one GPU)')
     ap.add_argument('--defer-nonfinite', action='store_true', help="read the optimiser's non-finite flag one step late (no per-step host sync)")
@@ -370,10 +386,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(objective, steps, warmup, conf=conf, batch=batch, dtype=dtype, fp8=fp8):
+    def timed_run(objective, steps, warmup, conf=conf, batch=batch, dtype=dtype, fp8=fp8, saved_e4m3=None):
         """W untimed + K timed steps of one objective; returns (seconds (max over ranks), final loss, probe result, ms per step of every rank)"""
         torch.manual_seed(77)  # identical initial weights on every rank (HipTrainStep broadcasts rank 0's anyway)
-        model = E.EcgVit(config=conf, compute_dtype=dtype, fp8_linear=fp8)
+        if args.bf16_aux:
+            saved_e4m3 = False
+        model = E.EcgVit(config=conf, compute_dtype=dtype, fp8_linear=fp8, saved_ffn_e4m3=saved_e4m3)
         if objective == 'masked':
             model = E.MaskedEcgVit(model, mask_ratio=0.5)
         model = model.to(dev).train()
@@ -388,8 +406,6 @@ def main():
                               sync_nonfinite=not args.defer_nonfinite, single_rank_collectives=args.single_rank_collectives,
                               grad_comm_dtype=torch.bfloat16 if args.grad_comm == 'bf16' else torch.float32)
         run_step = step.step_masked if objective == 'masked' else step.step
-        if args.bf16_aux:
-            (model.encoder if objective == 'masked' else model)._engine().aux8 = False
         probe = None
         if not args.no_probe and dtype == torch.bfloat16:
             probe = GemmProbe(E.hip, E.hip.GEMM_NT, torch.bfloat16)
@@ -431,7 +447,7 @@ def main():
                       + ('; e4m3 / e5m2 operands on the block-scaled fp8 MFMA, K-tile 128 deep' if r['launches_8bit'] else '') + ')',
             'bound': 'mfma', 'achieved': r['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': r['tflops'] / peak,
             'traffic': traffic, 'traffic_source': source, 'avg_launch_us': r['avg_us'], 'launches': r['launches'],
-            'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'],
+            'alg_flops_per_launch': r['flops_per_launch'], 'alg_bytes_per_launch': r['alg_bytes_per_launch'], 'bytes_model': BYTES_MODEL,
         }
 
     dt, final_loss, pres, rank_ms = timed_run(args.objective, args.steps, args.warmup)   # the headline run: its own per-rank times
@@ -445,7 +461,21 @@ def main():
             'workload': f'EcgVit-{args.config} masked-patch pre-train step (SimMIM-style: 50 % of the {n_patch} patches replaced by a mask token, no CLS, '
                         f'L1 reconstruction of the masked patches; fwd+loss+bwd+clip+AdamW), {dropout_desc(conf)}, {batch} records/GPU',
             'value': batch * msteps / mdt, 'unit': 'records/s', 'steps': msteps, 'ms_per_step': 1e3 * mdt / msteps, 'final_loss': mloss,
+            # at its OWN algorithmic FLOP count: 250 tokens (no CLS row), + the pixel head over the masked rows, no classification head
+            'model_tflops_per_gpu': batch * msteps / mdt * E.workload.masked_train_flops_per_record(conf, 0.5) / 1e12,
+            'mfma_frac_of_peak': batch * msteps / mdt * E.workload.masked_train_flops_per_record(conf, 0.5) / 1e12 / PEAK_BF16_TFLOPS,
             'roofline': roofline_of(mres, 'masked'),
+        }
+    bf16_saved_line = None
+    if args.objective == 'supervised' and world == 1 and args.config == 'base' and args.dtype == 'bf16' and not args.no_bf16_saved and not args.bf16_aux:
+        # the headline step keeps ONE backward-only tensor per layer (gelu'(pre) x dropout multiplier, [tokens, 3072]) as e4m3 bytes; this is the same
+        # step with that tensor in bf16 -- every stored tensor then has the metric's dtype -- timed by the same caller, same steps
+        bdt, bloss, _, _ = timed_run('supervised', args.steps, args.warmup, saved_e4m3=False)
+        bf16_saved_line = {
+            'workload': 'the headline step with saved_ffn_e4m3=False: the FFN backward tensor gelu\'(pre) x dropout multiplier stored as bf16 (2 bytes) instead of e4m3 (1 byte)',
+            'value': batch * args.steps / bdt, 'unit': 'records/s', 'steps': args.steps, 'ms_per_step': 1e3 * bdt / args.steps, 'final_loss': bloss,
+            'model_tflops_per_gpu': batch * args.steps / bdt * E.workload.train_flops_per_record(conf) / 1e12,
+            'mfma_frac_of_peak': batch * args.steps / bdt * E.workload.train_flops_per_record(conf) / 1e12 / PEAK_BF16_TFLOPS,
         }
 
     small_line = None
@@ -492,8 +522,15 @@ def main():
         }
 
     if rank == 0:
-        flops_rec = E.workload.train_flops_per_record(conf)
+        flops_rec = E.workload.masked_train_flops_per_record(conf, 0.5) if args.objective == 'masked' else E.workload.train_flops_per_record(conf)
         value = batch * world * args.steps / dt
+        storage_desc = ''
+        if dtype == torch.bfloat16:
+            e4 = not args.bf16_aux
+            storage_desc = ('; arithmetic bf16 MFMA / f32 accumulate, all activations stored bf16 EXCEPT one backward-only tensor per layer: the FFN\'s gelu\'(pre) x dropout '
+                            'multiplier [tokens, ffn] is kept between forward and backward as ' + ('e4m3 BYTES (3 mantissa bits, relative error <= 2^-4 per element, unbiased; forward '
+                            'values unaffected; the same step with it in bf16 is the nested bf16_saved_tensor object)' if e4 else 'bf16 (--bf16-aux)') +
+                            '; GELU / GELU\' of the bf16 path use a three-term erf (|error| <= 2.5e-5, below one bf16 ulp of the stored values)')
         out = {
             'metric': '12-lead ECG records/sec pre-train step, ViT-Base bf16 @ 1/2/4/8 MI355X' if args.config == 'base'
             else f'12-lead ECG records/sec train step, EcgVit-{args.config}',
@@ -504,15 +541,17 @@ def main():
             'config': {
                 'workload': f'EcgVit-{args.config} ' + ('masked-patch pre-train step (SimMIM-style, 50 % of patches masked, L1 recon; fwd+loss+bwd+clip+AdamW'
                             if args.objective == 'masked' else 'supervised BCE train step (reference train.py:271-283: fwd+loss+bwd+clip+AdamW') + (
-                            f'{"+RCCL all-reduce" if world > 1 else ""}), {dropout_desc(conf)}, '
+                            f'{"+RCCL all-reduce" if world > 1 else ""}), hidden {conf.hidden_size} x {conf.num_hidden_layers} layers x {conf.num_attention_heads} heads, '
+                            f'ffn {conf.intermediate_size}, {dropout_desc(conf)}, '
                             f'{batch} records/GPU x 12 leads x {conf.max_signal_length} samples, patch {conf.patch_size} '
-                            f'({conf.max_signal_length // conf.patch_size + (0 if args.objective == "masked" else 1)} tokens), random-init weights, inputs resident in HBM'),
+                            f'({conf.max_signal_length // conf.patch_size + (0 if args.objective == "masked" else 1)} tokens), random-init weights, inputs resident in HBM'
+                            + storage_desc),
                 'global_batch': batch * world, 'per_gpu_batch': batch, 'parallelism': f'dp{world}' + ('+single-rank-collectives' if args.single_rank_collectives else ''),
-                'hidden': conf.hidden_size, 'layers': conf.num_hidden_layers, 'heads': conf.num_attention_heads,
                 # what holds the timed path to the reference (tests/, -m gpu): stated next to the number it qualifies
                 'parity': 'f32 HIP path vs CPU oracle <= 1e-4 (loss, logits, every gradient; full-depth base, masked step at this geometry); bf16 path: loss <= 2e-2, '
-                          'whole-gradient cosine >= 0.98 at dropout 0; with dropout > 0 (as timed) the counter-based masks cannot equal torch\'s Philox stream: mask '
-                          'statistics and forward / backward mask agreement only; the oracle\'s transformer arithmetic restates vit-pytorch 0.33.2 (not installable here: parity unpinned)',
+                          'whole-gradient cosine >= 0.98, every tensor >= 0.95 -- at dropout 0 AND at dropout 0.1 as timed (tests/test_gpu_dropout_parity.py: the masks the HIP '
+                          'kernels drew are exported and injected into the oracle\'s five nn.Dropout sites, supervised and masked step, base layer shape, e4m3 saved tensor and '
+                          'quad 8-bit masks on); the oracle\'s transformer arithmetic restates vit-pytorch 0.33.2 (not installable here: parity unpinned)',
             },
             'final_loss': final_loss,
             'workload_key': workload_key(args), 'kernel_source_sha16': kernel_source_hash(),
@@ -523,6 +562,8 @@ def main():
         }
         if pres:
             out['roofline'] = roofline_of(pres, args.objective)
+        if bf16_saved_line:
+            out['bf16_saved_tensor'] = bf16_saved_line
         if masked_line:
             out['masked'] = masked_line
         if small_line:

@@ -185,7 +185,7 @@ class VitEngine:
             self.f8_amax = torch.zeros(ns, dtype=torch.float32, device=self.device)
             self.f8_fmt = torch.tensor(([hip.FP8_E4M3] * 4 + [hip.BF8_E5M2] * 4) * self.Ly, dtype=torch.int32, device=self.device)
             self._f8_seen = set()
-            self._f8_last_training, self._f8_trained = None, False
+            self._f8_last_training, self._f8_scale_train = None, None
 
     # ---------------------------------------------------------------- fp8 operand path
     def refresh_fp8_weights(self):
@@ -201,17 +201,20 @@ class VitEngine:
 
     def fp8_begin_step(self, training=True):
         """delayed scaling: the scales of this pass come from the amax the previous pass's quantise kernels accumulated.
-        One exception: a TRAINING pass that follows an EVAL pass keeps the scales of the last training pass (the eval pass's amax is discarded) --
-        eval activations carry no dropout, training tensors are rescaled by 1 / (1 - p) (the FFN hidden activation most of all), and scales are
-        amax / format-max with no headroom: scales taken from an eval pass would saturate the first training step after every evaluation."""
+        One exception: a TRAINING pass that follows EVAL passes resumes from the scales the last training pass left (snapshotted when the first eval
+        pass began; the eval passes' amax is discarded) -- eval activations carry no dropout, training tensors are rescaled by 1 / (1 - p) (the FFN
+        hidden activation most of all), and scales are amax / format-max with no headroom: scales taken from an eval pass would saturate the
+        first training step after every evaluation."""
         if self._f8_seen:
-            if training and self._f8_last_training is False and self._f8_trained:
+            if training and self._f8_last_training is False and self._f8_scale_train is not None:
+                self.f8_scale.copy_(self._f8_scale_train)
                 self.f8_amax.zero_()
             else:
                 check(lib().ecgvit_fp8_scale_update(ptr(self.f8_scale), ptr(self.f8_amax), self.f8_scale.numel(), ptr(self.f8_fmt), 0, stream()),
                       'fp8_scale_update')
+                if not training and self._f8_last_training:
+                    self._f8_scale_train = self.f8_scale.clone()   # train -> eval: what the last training pass's amax gave (8 floats per layer)
         self._f8_last_training = bool(training)
-        self._f8_trained = self._f8_trained or bool(training)
 
     def _quant(self, site, x, count, out=None):
         """x (bf16, `count` elements) -> `out` (a layer's persistent e4m3 copy: the weight-gradient product reads it again in the

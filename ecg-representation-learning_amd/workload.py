@@ -28,3 +28,12 @@ def forward_flops_per_record(cfg, num_class=71, cls_token=True):
 def train_flops_per_record(cfg, num_class=71):
     """train step = 3 x forward (no recomputation credited)"""
     return 3 * forward_flops_per_record(cfg, num_class)
+
+
+def masked_train_flops_per_record(cfg, mask_ratio=0.5):
+    """the masked pre-train step at its own count: trunk over the n patch tokens (no CLS row), patch embed, the pixel head
+    Linear(d, C*P) over the m = max(1, int(ratio * n)) masked rows, no classification head; train = 3 x forward"""
+    n = cfg.max_signal_length // cfg.patch_size
+    d, f, ly, cp = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_channels * cfg.patch_size
+    m = max(1, int(mask_ratio * n))
+    return 3 * (2 * n * cp * d + ly * (8 * n * d * d + 4 * n * d * f + 4 * n * n * d) + 2 * m * d * cp)

@@ -183,7 +183,7 @@ def test_bench_self_launcher_single_rank_collectives():
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--single-rank-collectives', '--steps', '3', '--warmup', '1',
-                        '--no-cpu-baseline', '--no-masked', '--no-small', '--no-fp8-large', '--batch', '64'], env=env, capture_output=True, text=True, timeout=900)
+                        '--no-cpu-baseline', '--no-masked', '--no-bf16-saved', '--no-small', '--no-fp8-large', '--batch', '64'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1

@@ -11,9 +11,9 @@ for r in $(seq $REPS); do
   for v in $VALS; do
     echo -n "rep $r $VAR=$(basename $v): "
     if [[ $VAR == --* ]]; then
-      python bench.py --no-cpu-baseline --no-masked --no-small --no-fp8-large --steps 20 --warmup 5 $VAR $v "$@" 2>&1
+      python bench.py --no-cpu-baseline --no-masked --no-bf16-saved --no-small --no-fp8-large --steps 20 --warmup 5 $VAR $v "$@" 2>&1
     else
-      env $VAR=$v python bench.py --no-cpu-baseline --no-masked --no-small --no-fp8-large --steps 20 --warmup 5 "$@" 2>&1
+      env $VAR=$v python bench.py --no-cpu-baseline --no-masked --no-bf16-saved --no-small --no-fp8-large --steps 20 --warmup 5 "$@" 2>&1
     fi | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"frac": [0-9.]*\|"avg_launch_us": [0-9.]*' | tr '\n' ' '
     echo
   done

@@ -90,6 +90,11 @@ def check(profiles=None, verbose=True):
             errors.append(f'{name}: roofline.frac {roof["frac"]:.4f} vs {frac:.4f} recomputed from {sname}\'s stats CSV ({calls} launches, {tot / calls / 1e3:.1f} us avg): {100 * rel:.1f} % apart')
         elif verbose:
             print(f'ok  {name}: roofline.frac {roof["frac"]:.4f} vs {frac:.4f} from {sname} ({tot / calls / 1e3:.1f} us avg over {calls} launches)')
+        if roof.get('traffic') is not None and verbose:
+            # traffic / algorithmic bytes is only comparable between lines that count the same streams: bench.BYTES_MODEL (absent: rounds <= 4 counted
+            # operands + output = model 1; round 5's line already counted the epilogue streams = model 2 without saying so)
+            bm = roof.get('bytes_model', 2 if name.startswith('r05') else 1)
+            print(f'    {name}: traffic / algorithmic bytes = {roof["traffic"] / roof["alg_bytes_per_launch"]:.2f} (bytes model {bm}; compare only with lines of the same model)')
         if roof.get('traffic') is not None and abs(roof['traffic'] - s['kernels']['gemm_nt'].get('hbm_bytes_per_launch', -1)) > 1:
             errors.append(f'{name}: roofline.traffic {roof["traffic"]} is not {sname}\'s gemm_nt hbm_bytes_per_launch')
     # text tables that name their sources: same hash as the round's bench line

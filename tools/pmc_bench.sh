@@ -13,7 +13,7 @@ case " $* " in *" --single-rank-collectives "*|*" --gpus "[2-9]*) [ -n "$WORLD_S
 SHA=$(cd $R && python3 -c "import bench; print(bench.kernel_source_hash())") || exit 1
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/pmc_${TAG}_${SHA}; rm -rf "$O"; mkdir -p "$O"
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-small --no-fp8-large $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-bf16-saved --no-small --no-fp8-large $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $ARGS > $O/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_VMEM" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES"; do
   T=$(echo $C | tr ' ' '+' | cut -c1-40)

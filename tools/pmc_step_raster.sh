@@ -4,7 +4,7 @@
 : "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT is the repo copy on the GPU box)}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_step_raster; rm -rf $O; mkdir -p $O
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-small --no-fp8-large --hip-lib $R/ecg-representation-learning_amd/csrc/build/libecgvit_hip_tools.so"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-bf16-saved --no-small --no-fp8-large --hip-lib $R/ecg-representation-learning_amd/csrc/build/libecgvit_hip_tools.so"
 for G in ${1:-0 6}; do
   export ECGVIT_NT_G=$G
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/steady_$TAG; rm -rf "$O"; mkdir -p "$O"
 for S in 2 6; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/s$S -- python3 $R/bench.py --steps $S --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-small --no-fp8-large "$@" > $O/s$S.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/s$S -- python3 $R/bench.py --steps $S --warmup 1 --no-cpu-baseline --no-probe --no-masked --no-bf16-saved --no-small --no-fp8-large "$@" > $O/s$S.log 2>&1
 done
 python3 - "$O" "$R" "$TAG" "$@" <<'PY' > $R/gpurun_out/steady_$TAG.txt
 import csv, glob, sys, os
