@@ -235,8 +235,13 @@ def cpu_baseline(conf, seconds_budget=25.0, masked=False):
     b = max(1, min(16, int(seconds_budget / 10.0 / max(t1, 1e-3))))   # ~ len(cands) probe steps + a warm-up + >= 2 timed steps inside the budget
     x, y = batch_of(b)
     tr.step(x, y)  # warm-up at the timed shape
-    probe_s = {}
+    probe_s, skipped = {}, []
     for t in cands:
+        # ascending; once a step takes more than twice the best so far, larger thread counts are not run (torch eager's intra-op pool gets slower, not
+        # faster, past the point where it stops scaling: 256 threads took 185 s for a step that 16 threads do in 0.8 s on a 2 x 64-core EPYC 9575F)
+        if probe_s and min(probe_s.values()) * 2.0 < list(probe_s.values())[-1]:
+            skipped.append(t)
+            continue
         torch.set_num_threads(t)
         t0 = time.perf_counter()
         tr.step(x, y)
@@ -250,6 +255,8 @@ def cpu_baseline(conf, seconds_budget=25.0, masked=False):
         n += 1
     dt = time.perf_counter() - t0
     probes = ', '.join(f'{t}: {b / v:.2f} rec/s' for t, v in probe_s.items())
+    if skipped:
+        probes += f'; {"/".join(str(t) for t in skipped)} (= all cores) not run: throughput had already fallen to less than half of the best'
     return dict(value=b * n / dt, unit='records/s', cores=cores, kind='port', cpu_model=cpu_model_name(), cores_available=avail,
                 sample=f'{n} full train steps (fwd+BCE+bwd+clip+AdamW, torch eager f32) of the same model on {b} synthetic '
                        f'12x{conf.max_signal_length} records, {cores} threads of {avail} available (fastest of one {b}-record step each at threads {probes})',

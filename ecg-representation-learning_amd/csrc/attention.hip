@@ -249,6 +249,251 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 }
 
 // =====================================================================================================
+// forward, STREAMED (round 6): ONE persistent 16-wave workgroup per CU; the K / V rows arrive as a continuous stream of 64-KiB windows through a
+// two-slot ring of LDS-DMA images that runs across (record, head) items -- every wave computes window t while the pieces of window t + 1 are in
+// flight, four waves per SIMD compute all the time, nothing is relaunched and nothing drains.
+//   GROUPS = 2 (N <= 256): waves 0-7 / 8-15 own two items side by side, a window = 128 keys of each (K 16 KiB + V 16 KiB per item);
+//   GROUPS = 1 (256 < N <= 512): the 16 waves are the 16 query blocks of ONE item, a window = 256 of its keys (K 32 KiB + V 32 KiB) -- the K / V
+//                rows of an item are read ONCE (the split one-item form read them once per 256-query half: 1.6 x the algorithmic bytes at 501 tokens).
+// The online softmax of the one-item kernel already carries (m, l, O) across key tiles, so a window boundary changes no arithmetic: outputs, LSE and
+// dropout masks are BIT-IDENTICAL to attn_fwd_bf16_kernel (tests/test_gpu_ops.py holds the two against each other).
+// One barrier per window: [my pieces of window t landed: counted vmcnt] -> barrier (window t complete, everyone done with window t - 1: its slot
+// is free) -> issue the pieces of window t + 1 -> compute window t.  vmcnt retires in issue order, and every wave issues a FIXED number of vector-memory
+// operations behind the pieces of an item's first window (the next Q fragments -- requested behind the item's last Q.K^T product, into the registers it
+// frees -- and NST output stores, all bounds-checked buffer operations: rows >= N are dropped by the descriptor, never branched around), so the wait for
+// those pieces is vmcnt(NST): the previous item's stores stay in flight under the next item's first window (a one-item kernel drains them with its
+// sixteen waves idle: profiles/r05_attn_ablation.txt).  V^T fragments are inline-asm transposed reads (hipcc drains vmcnt(0) in front of the builtin
+// form when an LDS-DMA is in flight: attn_common.h), requested at the top of a tile and consumed behind its softmax.
+// =====================================================================================================
+template <bool DROP, bool Q8, int GROUPS>
+__global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, float *__restrict__ lse, int N, int h,
+                                                               float scale, uint64_t seed, uint32_t thresh, float inv_keep, int nitems,
+                                                               uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
+                                                               float *__restrict__ q8_amax = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 slots x 64 KiB
+    constexpr int WG_ = 16 / GROUPS;      // waves = 32-query blocks per item
+    constexpr int WK = 256 / GROUPS;      // keys per window
+    constexpr int TPW = WK / 32;          // key tiles per window
+    constexpr int GB = WK * 256;          // bytes of one group's K + V images inside a slot
+    constexpr int NST = Q8 ? 7 : 5;       // vector-memory operations a wave issues behind its Q request: 4 output stores of 16 B (+ 2 of the 8-bit copy) + the LSE store
+    [[maybe_unused]] unsigned int amax_seen = 0u;
+    if constexpr (Q8) amax_seen = amax_peek(q8_amax);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int group = GROUPS == 2 ? wave >> 3 : 0, wq = GROUPS == 2 ? wave & 7 : wave;
+    const int nkt = (N + 31) >> 5, nw = (nkt + TPW - 1) / TPW;
+    const int nsuper = (nitems + GROUPS - 1) / GROUPS;
+    const int d = h * 64;
+    const int d3 = 3 * d;
+    const int lr = lane & 31, lh = lane >> 5;
+    const float c = scale * 1.44269504088896340736f;
+    const RowOff ro = make_row_off(lane);
+    const TrOff to = make_tr_off(lane);
+    const uint32_t smix = seed_mix(seed);
+    [[maybe_unused]] const uint32_t c4 = quad_c4(thresh);
+    [[maybe_unused]] const bool t_hi = thresh >= 128u;
+    const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_o = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
+    const int q = wq * 32 + lr;                       // my query of the item (rows >= N: loads return 0, stores are dropped)
+    const int qoff = (q * d3 + 8 * lh) * 2;
+
+    // pieces of window w of super-item s -> slot; my group's item only (an item past the end: nothing is issued, its waves keep the barriers company)
+    auto issue = [&](int s, int w, int slot) __attribute__((always_inline)) {
+        const int item = s * GROUPS + group;
+        if (item >= nitems) return;
+        const int b = item / h, hd = item - b * h;
+        const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
+        const int k0 = w * WK, nv = min(WK, N - k0), rp = ((nv + 31) >> 5) << 5;
+        char *Kimg = smem + slot * 65536 + group * GB;
+        dma_image<WG_>(Kimg, base + d + (int64_t)k0 * d3, d3, nv, rp, wq, lane);
+        dma_image<WG_>(Kimg + WK * 128, base + 2 * d + (int64_t)k0 * d3, d3, nv, rp, wq, lane);
+    };
+    // the item's Q fragments as inline-asm buffer loads: hipcc's waitcnt pass would guard every use of a loop-carried load with vmcnt(0) -- in EVERY
+    // tile, draining the next window's pieces in front of the window they are supposed to land under; issued this way the pass does not see them, and the
+    // counted wait at the item's first window (vmcnt(NST): they are older than the stores) orders them by hand
+    auto load_q = [&](int s, bf16x8 (&qf)[4]) __attribute__((always_inline)) {
+        const int item = s * GROUPS + group;
+        if (item >= nitems) return;
+        const int b = item / h, hd = item - b * h;
+        const uint64_t pa = (uint64_t)(uintptr_t)(qkv + (int64_t)b * N * d3 + hd * 64);
+        const i32x4_t rq = i32x4_t{(int)(uint32_t)pa, (int)((pa >> 32) & 0xFFFFu), (int)bytes_q, 0x00020000};
+        asm volatile("buffer_load_dwordx4 %0, %4, %5, 0 offen\n\tbuffer_load_dwordx4 %1, %4, %5, 0 offen offset:32\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:64\n\tbuffer_load_dwordx4 %3, %4, %5, 0 offen offset:96"
+                     : "=&v"(qf[0]), "=&v"(qf[1]), "=&v"(qf[2]), "=&v"(qf[3]) : "v"(qoff), "s"(rq) : "memory");
+    };
+
+    int s = blockIdx.x;
+    if (s >= nsuper) return;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = bf16x8{};
+    issue(s, 0, 0);
+    load_q(s, qf);
+    int t = 0;                                        // windows this workgroup has started: slot = t & 1
+    for (; s < nsuper; s += gridDim.x) {
+        const int item = s * GROUPS + group;
+        const bool live = item < nitems;
+        const int bh = live ? item : 0;
+        const int b = bh / h, hd = bh - b * h;
+        const int snext = s + (int)gridDim.x;
+        const uint32_t rowquad = ((uint32_t)bh * (uint32_t)N + (uint32_t)(q < N ? q : N - 1)) * (uint32_t)((N + 3) >> 2);
+        f32x16 o[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        for (int w = 0; w < nw; ++w, ++t) {
+            // my pieces of window t have landed (an item's first window: behind them stand my Q request -- landed too, it is older than the stores --
+            // and the previous item's NST stores, which stay in flight); then the barrier
+            if (w == 0 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // (LDS-DMA writes and LDS reads only: no fence -- __syncthreads() would wait for the stores in flight)
+            if (w + 1 < nw) issue(s, w + 1, (t + 1) & 1);
+            else if (snext < nsuper) issue(snext, 0, (t + 1) & 1);
+            if (!live) continue;
+            const char *Kimg = smem + (t & 1) * 65536 + group * GB, *Vimg = Kimg + WK * 128;
+            const int ntile = min(TPW, nkt - w * TPW);
+            for (int ktl = 0; ktl < ntile; ++ktl) {
+                const int kt = w * TPW + ktl;
+                // V^T fragments of this tile: requested now, consumed behind the softmax (8 transposed reads, 16 registers)
+                bf16x4 vt[2][2][2];
+                {
+                    const uint32_t va = lds_addr_of(Vimg + ktl * 4096);
+#pragma unroll
+                    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            vt[ss][dt][0] = ss ? tr_read_asm_o<2048>(va + to.lo[dt]) : tr_read_asm_o<0>(va + to.lo[dt]);
+                            vt[ss][dt][1] = ss ? tr_read_asm_o<2048>(va + to.hi[dt]) : tr_read_asm_o<0>(va + to.hi[dt]);
+                        }
+                }
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_c(Kimg + ktl * 4096, ro.ks[ks]), qf[ks], sc, 0, 0, 0);
+                if (kt == nkt - 1) {  // the item's last tile: padded keys, and the Q fragments are dead -- request the next item's into their registers
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key >= N) sc[r] = -INFINITY;
+                    }
+                    if (snext < nsuper) load_q(snext, qf);
+                }
+                float mx = sc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (__any((mx - m) * c > 8.0f)) {     // lazy running maximum: attn_fwd_bf16_kernel
+                    const float mn = fmaxf(m, mx);
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+                    m = mn;
+                    l *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                }
+                const float mc = m * c;
+                float ls = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], c, -mc));
+                    sc[r] = p;
+                    ls += p;
+                }
+                l += ls;
+                u32x4 pk[2];
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(sc, ss));
+                if constexpr (DROP) {
+                    // dropout on the PACKED probabilities: per key quad (one hash word, 8 bits per key: the one-item kernel's mask bit for bit) the keep bits in
+                    // three bit-parallel instructions, per packed pair one byte permute + one packed arithmetic shift + one AND
+                    const uint32_t hb = (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t x = quad_keepbits(pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL), c4, t_hi);
+#pragma unroll
+                        for (int pp = 0; pp < 2; ++pp) {
+                            const uint32_t wv = __builtin_amdgcn_perm(x, x, pp ? 0x030C020Cu : 0x010C000Cu);
+                            pk[g >> 1][2 * (g & 1) + pp] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, wv) >> (s16x2_t){15, 15});
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, pk[ss]);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(join_halves(vt[ss][dt][0], vt[ss][dt][1]), pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (!live) continue;
+        l += __shfl_xor(l, 32, 64);
+        // output rows: the one-item kernel's 16-B runs (one v_permlane32_swap per dword), as bounds-checked buffer stores
+        {
+            [[maybe_unused]] float qmax = 0.f;
+            const float inv = inv_keep / l;
+            [[maybe_unused]] float q8_inv = 0.f;
+            if constexpr (Q8) { const float sc8 = *q8_scale; q8_inv = sc8 > 0.f ? 1.0f / sc8 : 0.f; }
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (int64_t)b * N * d + hd * 64), 0, bytes_o, 0x00020000);
+            const int ooff = (q * d + 16 * lh) * 2;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                [[maybe_unused]] u32x4 w8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t D[2][2];
+                    [[maybe_unused]] uint32_t W8[2];
+#pragma unroll
+                    for (int gg = 0; gg < 2; ++gg) {
+                        const int g4 = j + 2 * gg;
+                        bf16x4 v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = (bf16_t)(o[dt][4 * g4 + k] * inv);
+                        const u32x2 vv = __builtin_bit_cast(u32x2, v);
+                        D[gg][0] = vv[0]; D[gg][1] = vv[1];
+                        if constexpr (Q8) {
+                            float f[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                f[k] = (float)v[k];
+                                qmax = fmaxf(qmax, q < N ? fabsf(f[k]) : 0.f);
+                                f[k] = __builtin_amdgcn_fmed3f(f[k] * q8_inv, -448.f, 448.f);
+                            }
+                            int wv = 0;
+                            wv = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], wv, false);
+                            wv = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], wv, true);
+                            W8[gg] = (uint32_t)wv;
+                        }
+                    }
+                    u32x4 st;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(D[0][k], D[1][k], false, false);
+                        st[k] = sw[0]; st[2 + k] = sw[1];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(st, rout, ooff + (dt * 32 + 8 * j) * 2, 0, 0);
+                    if constexpr (Q8) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(W8[0], W8[1], false, false);
+                        w8[2 * j] = sw[0]; w8[2 * j + 1] = sw[1];
+                    }
+                }
+                if constexpr (Q8) {
+                    const __amdgpu_buffer_rsrc_t rout8 = __builtin_amdgcn_make_buffer_rsrc((void *)(out8 + (int64_t)b * N * d + hd * 64), 0, bytes_o / 2, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(w8, rout8, q * d + 16 * lh + dt * 32, 0, 0);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)(lse + (int64_t)bh * N), 0, (uint32_t)N * 4u, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m * scale + logf(l)), rl, lh == 0 ? q * 4 : 0x7FFFFFF0, 0, 0);
+            if constexpr (Q8) wave_amax_publish(q8_amax, qmax, amax_seen);
+        }
+    }
+}
+
+// =====================================================================================================
 // backward
 // =====================================================================================================
 template <int NKT, bool DROP>
@@ -1080,6 +1325,8 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16_t *__restric
 #ifdef ECGVIT_TOOLS
 static int g_tools_attn_variant = -1;
 extern "C" int ecgvit_tools_attn_variant(int v) { g_tools_attn_variant = v; return ECGVIT_OK; }
+static int g_tools_attn_fwd_variant = -1;   // -1: the product's dispatch; 0: always the one-item forward; 1: always the streamed forward
+extern "C" int ecgvit_tools_attn_fwd_variant(int v) { g_tools_attn_fwd_variant = v; return ECGVIT_OK; }
 #endif
 
 extern "C" {
@@ -1105,6 +1352,41 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
+    // the STREAMED form (one persistent 16-wave workgroup per CU, K / V windows through a two-slot ring) once there is a workgroup's worth of
+    // (record, head) items per CU; below that the one-item kernel, whose B*h workgroups spread over more CUs
+    {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return ECGVIT_ELAUNCH;
+            n_cu = v;
+        }
+        const int groups = N > 256 ? 1 : 2, nsuper = (B * h + groups - 1) / groups;
+        bool stream_form = nsuper >= n_cu && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
+#ifdef ECGVIT_TOOLS
+        if (g_tools_attn_fwd_variant == 0) stream_form = false;
+        if (g_tools_attn_fwd_variant == 1) stream_form = (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
+#endif
+        if (stream_form) {
+            static bool sattr = false;
+            if (!sattr) {
+#define SATTR(DR, Q, G) if (hipFuncSetAttribute((const void *)attn_fwd_stream_kernel<DR, Q, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ECGVIT_ELAUNCH
+                SATTR(true, false, 1); SATTR(false, false, 1); SATTR(true, true, 1); SATTR(false, true, 1);
+                SATTR(true, false, 2); SATTR(false, false, 2); SATTR(true, true, 2); SATTR(false, true, 2);
+#undef SATTR
+                sattr = true;
+            }
+            const dim3 sg((unsigned)(nsuper < n_cu ? nsuper : n_cu));
+#define SFWD(DR, Q, G) hipLaunchKernelGGL((attn_fwd_stream_kernel<DR, Q, G>), sg, dim3(1024), 128 * 1024, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, B * h, (uint8_t *)out8, q8_scale, q8_amax)
+#define SFWD2(DR, Q) do { if (groups == 1) SFWD(DR, Q, 1); else SFWD(DR, Q, 2); } while (0)
+            if (out8) { if (th) SFWD2(true, true); else SFWD2(false, true); }
+            else { if (th) SFWD2(true, false); else SFWD2(false, false); }
+#undef SFWD2
+#undef SFWD
+            ECGVIT_CHECK_LAUNCH();
+            return ECGVIT_OK;
+        }
+    }
     const bool split = N > 256;   // two 256-key windows through 64 KiB of images, one workgroup per 256-query half
     dim3 grid((unsigned)(B * h * (split ? (N + 255) / 256 : 1)));
     const size_t lds = split ? (size_t)256 * 128 * 2 : (size_t)((N + 31) / 32) * 32 * 128 * 2;

@@ -373,6 +373,52 @@ def test_attention_bf16_fwd_bwd(N):
         assert rel_err(got, ref) < 2e-2, (nm, rel_err(got, ref))
 
 
+@pytest.mark.parametrize('B,h,N,p', [(171, 3, 251, 0.1), (100, 6, 251, 0.0), (33, 4, 130, 0.1), (9, 6, 64, 0.1), (5, 3, 1, 0.0), (60, 5, 501, 0.1), (70, 4, 300, 0.0),
+                                     (52, 5, 257, 0.1), (64, 4, 512, 0.1), (43, 6, 449, 0.0), (7, 1, 251, 0.3), (3, 1, 501, 0.3), (40, 12, 200, 0.1)])
+def test_attention_fwd_streamed_equals_one_item_kernel(B, h, N, p):
+    """the STREAMED forward (round 6: one persistent 16-wave workgroup per CU, K / V windows through a two-slot LDS-DMA ring that runs across items, counted
+    waits) against the one-(record, head)-per-workgroup forward on the same inputs, seed and dropout rate: output, LSE -- and with them the dropout mask --
+    BIT-IDENTICAL (a window boundary changes no arithmetic of the online softmax); repeated launches identical (a ring race would show); odd item
+    counts (the second wave group idles in the last pair), one or several items per workgroup, one / two windows per item, a one-key last window (257)"""
+    tl = tools_lib()
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    dh = 64
+    d = h * dh
+    qkv = dev((torch.randn(B * N, 3 * d, generator=g) * 1.3).to(BF16))
+    res = {}
+    try:
+        for variant in (0, 1):
+            tl.ecgvit_tools_attn_fwd_variant(variant)
+            for rep in range(4 if variant else 1):
+                out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
+                lse = torch.full((B * h * N,), float('nan'), device='cuda')
+                check(tl.ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, dh, dh ** -0.5, p, 4321, hip.BF16, stream()), 'attn_fwd')
+                torch.cuda.synchronize()
+                if rep == 0:
+                    res[variant] = (out, lse)
+                else:
+                    assert torch.equal(out.view(torch.int16), res[variant][0].view(torch.int16)) and torch.equal(lse, res[variant][1]), rep
+    finally:
+        tl.ecgvit_tools_attn_fwd_variant(-1)
+    assert torch.isfinite(res[1][0].float()).all() and torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_attention_fwd_product_dispatch_takes_the_streamed_kernel_at_full_occupancy():
+    """the product library picks the streamed forward once there is a workgroup's worth of items per CU (2 items per workgroup up to 256 tokens): at
+    600 x 1 x 251 / 300 x 1 x 501 it must agree with the double-precision reference like the one-item kernel does at the small shapes above"""
+    for B, h, N in ((600, 1, 251), (300, 1, 501)):
+        g = torch.Generator().manual_seed(N)
+        qkv = (torch.randn(B * N, 3 * 64, generator=g) * 1.5).to(BF16)
+        out = torch.full((B * N, 64), float('nan'), device='cuda', dtype=BF16)
+        lse = torch.zeros(B * h * N, device='cuda')
+        check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, 64, 0.125, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
+        o_ref, lse_ref, _ = _attn_ref(qkv.double(), B, N, h, 64, 0.125)
+        assert torch.isfinite(out.float()).all()
+        assert max_err(out, o_ref) < 2e-2 and rel_err(out, o_ref) < 1e-2 and max_err(lse.view(B, h, N), lse_ref) < 2e-3
+
+
 @pytest.mark.parametrize('N', [251, 501])
 @pytest.mark.parametrize('shape', ['rising', 'falling', 'spike'])
 def test_attention_fwd_lazy_running_maximum(N, shape):

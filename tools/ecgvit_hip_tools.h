@@ -22,6 +22,8 @@ int ecgvit_attention_bwd_oneitem(const void *qkv, const void *out, const void *d
  * round 3 shipped, 3 / 4 / 5: priority variants).  tools/attn_variants.py, tools/attn_ab.py.  (-2 selected round 4's four-wave experiment
  * while it was part of the tools build: tools/experiments/.) */
 int ecgvit_tools_attn_variant(int v);
+/* forward: -1 (default) the product's dispatch; 0: always the one-item-per-workgroup forward; 1: always the streamed forward (round 6) */
+int ecgvit_tools_attn_fwd_variant(int v);
 /* device buffer of 768 x 128 (+ per-phase records) uint64 that the eight-wave persistent backward fills with cycle stamps; NULL = off */
 int ecgvit_debug_attn_stamps(void *buf);
 

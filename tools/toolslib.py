@@ -26,6 +26,7 @@ def tools_lib():
         l.ecgvit_probe_mfma_layout.restype, l.ecgvit_probe_mfma_layout.argtypes = I, [P, P]
         l.ecgvit_attention_bwd_oneitem.restype, l.ecgvit_attention_bwd_oneitem.argtypes = I, [P, P, P, P, P, I, I, I, I, F, F, U, I, P]
         l.ecgvit_tools_attn_variant.restype, l.ecgvit_tools_attn_variant.argtypes = I, [I]
+        l.ecgvit_tools_attn_fwd_variant.restype, l.ecgvit_tools_attn_fwd_variant.argtypes = I, [I]
         l.ecgvit_debug_attn_stamps.restype, l.ecgvit_debug_attn_stamps.argtypes = I, [P]
         _tools = l
     return _tools
