@@ -40,6 +40,60 @@ __device__ unsigned long long *g_attn_stamps = nullptr;   // diagnostics (ecgvit
 #else
 #define ATTN_ABL(n) false
 #endif
+// ---- the vector phase of one 32-key x 32-query score tile, shared by both forward kernels (so that they agree bit for bit): lazy running maximum,
+// p = exp2(s c - m c) and the row sum two elements per instruction (v_pk_fma_f32 / v_pk_add_f32: the same IEEE operations per element; the sum runs
+// as two interleaved partial sums), packed to bf16, dropout applied to the PACKED pairs -- per key quad (one hash word, 8 bits per key) the keep bits
+// in three bit-parallel instructions (the >= / < 128 threshold forms are ONE three-input bit operation on a uniform mask), per pair one byte permute,
+// one packed arithmetic shift, one AND.  ~9 vector instructions per score element instead of ~11 (round 6).
+template <bool DROP>
+__device__ __forceinline__ void attn_fwd_tile_vec(f32x16 &sc, float &m, float &l, f32x16 (&o)[2], float c, uint32_t hb, uint32_t c4, uint32_t thi_mask,
+                                                  u32x4 (&pk)[2]) {
+    float mx = sc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // (NOT v_permlane32_swap(mx, mx): with one value as both operands hipcc treats the two results as equal)
+    // LAZY running maximum: the reference m of a query moves only when a tile's maximum exceeds it by more than 2^8 in the exponent, so a tile's
+    // probabilities are at most 256 relative to it (bf16 / f32 keep the same relative precision there; the sums stay far inside f32) and the common
+    // tile has no exponential of alpha and no rescale of the 32 output accumulators.  The exact maximum is not needed: out = sum(p v) / sum(p) and
+    // LSE = m scale + log(sum p) hold for any reference m.  Wave-uniform branch; always taken on the first tile (m = -inf).
+    if (__any((mx - m) * c > 8.0f)) {
+        const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0; lanes that do not move: 1
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    const f32x2 c2 = {c, c}, nmc = {-m * c, -m * c};
+    f32x2 ls2 = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 a = __builtin_elementwise_fma(f32x2{sc[r], sc[r + 1]}, c2, nmc);   // argument <= 8
+        const f32x2 p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+        sc[r] = p[0]; sc[r + 1] = p[1];
+        ls2 += p;
+    }
+    l += ls2[0] + ls2[1];                           // per-half partial sums; halves are combined after the loop
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(sc, ss));
+    if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout); the 1/(1-p) rescale is folded
+        // into the final normalisation.  My 16 keys are 4 quads: kt*32 + 8g + 4*lh + {0..3}; dword j of pk[ss] = keys (2 (j & 1), + 1) of quad 2 ss + (j >> 1)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t hh = pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL);
+            const uint32_t x1 = (hh & 0x7F7F7F7Fu) + c4;
+            const uint32_t x = (x1 & hh & thi_mask) | ((x1 | hh) & ~thi_mask);      // bit 7 of byte k: keep(key k) -- quad_keepbits for either threshold range
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+                const uint32_t wv = __builtin_amdgcn_perm(x, x, pp ? 0x030C020Cu : 0x010C000Cu);
+                pk[g >> 1][2 * (g & 1) + pp] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, wv) >> (s16x2_t){15, 15});
+            }
+        }
+    }
+}
+
 template <bool DROP, bool Q8 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out,
                                                                float *__restrict__ lse, int N, int h, float scale,
@@ -130,49 +184,16 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
                     if (key >= N) s[r] = -INFINITY;
                 }
             }
+            u32x4 pk[2];
             if constexpr (!ATTN_ABL(8)) {
-            float mx = s[0];
+                attn_fwd_tile_vec<DROP>(s, m, l, o, c, (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix, quad_c4(thresh), thresh >= 128u ? ~0u : 0u, pk);
+            } else {
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // (NOT v_permlane32_swap(mx, mx): with one value as both operands hipcc treats the two results as equal)
-            // LAZY running maximum: the reference m of a query moves only when a tile's maximum exceeds it by more than 2^8 in the exponent, so a tile's
-            // probabilities are at most 256 relative to it (bf16 / f32 keep the same relative precision there; the sums stay far inside f32) and the common
-            // tile has no exponential of alpha and no rescale of the 32 output accumulators (16 packed multiplies that cost double beside the MFMAs: ~15 % of
-            // a tile's vector work).  The exact maximum is not needed: out = sum(p v) / sum(p) and LSE = m scale + log(sum p) hold for any reference m.
-            // Wave-uniform branch; always taken on the first tile (m = -inf), after that only when attention is peaked enough to jump by 2^8.
-            if (__any((mx - m) * c > 8.0f)) {
-                const float mn = fmaxf(m, mx);                 // finite from tile 0 on (key 0 is always valid)
-                const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);   // raw v_exp_f32; m = -inf on the first tile -> 0; lanes that do not move: 1
-                m = mn;
-                l *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            }
-            const float mc = m * c;
-            float ls = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c, -mc));   // one fma per score (the kernel is VALU-bound); argument <= 8
-                s[r] = p;
-                ls += p;
-            }
-            l += ls;                                        // per-half partial sums; halves are combined after the loop
-            if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout); the
-                // 1/(1-p) rescale is folded into the final normalisation.  My 16 keys are 4 quads: kt*32 + 8g + 4*lh + {0..3}
-                const uint32_t hb = (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint32_t hh = pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) s[4 * g + k] = ((hh >> (8 * k)) & 0xFFu) >= thresh ? s[4 * g + k] : 0.f;
-                }
-            }
+                for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(s, ss));
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                const bf16x8 pf = pack8(s, ss);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, pk[ss]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     if constexpr (ATTN_ABL(10)) { asm volatile("" : "+v"(o[dt]) : "v"(pf)); continue; }
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__r
     const TrOff to = make_tr_off(lane);
     const uint32_t smix = seed_mix(seed);
     [[maybe_unused]] const uint32_t c4 = quad_c4(thresh);
-    [[maybe_unused]] const bool t_hi = thresh >= 128u;
+    [[maybe_unused]] const uint32_t thi_mask = thresh >= 128u ? ~0u : 0u;
     const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_o = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
     const int q = wq * 32 + lr;                       // my query of the item (rows >= N: loads return 0, stores are dropped)
     const int qoff = (q * d3 + 8 * lh) * 2;
@@ -354,17 +375,22 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__r
             const int ntile = min(TPW, nkt - w * TPW);
             for (int ktl = 0; ktl < ntile; ++ktl) {
                 const int kt = w * TPW + ktl;
-                // V^T fragments of this tile: requested now, consumed behind the softmax (8 transposed reads, 16 registers)
+                // V^T fragments of this tile: requested now, consumed behind the softmax (8 transposed reads, 16 registers; the emitting dropout
+                // instantiation has 8 registers less to spare: its second half is requested behind the softmax)
+                constexpr bool VLATE = Q8 && DROP;
                 bf16x4 vt[2][2][2];
-                {
-                    const uint32_t va = lds_addr_of(Vimg + ktl * 4096);
+                const uint32_t va = lds_addr_of(Vimg + ktl * 4096);
 #pragma unroll
-                    for (int ss = 0; ss < 2; ++ss)
+                for (int dt = 0; dt < 2; ++dt) {
+                    vt[0][dt][0] = tr_read_asm_o<0>(va + to.lo[dt]);
+                    vt[0][dt][1] = tr_read_asm_o<0>(va + to.hi[dt]);
+                }
+                if constexpr (!VLATE) {
 #pragma unroll
-                        for (int dt = 0; dt < 2; ++dt) {
-                            vt[ss][dt][0] = ss ? tr_read_asm_o<2048>(va + to.lo[dt]) : tr_read_asm_o<0>(va + to.lo[dt]);
-                            vt[ss][dt][1] = ss ? tr_read_asm_o<2048>(va + to.hi[dt]) : tr_read_asm_o<0>(va + to.hi[dt]);
-                        }
+                    for (int dt = 0; dt < 2; ++dt) {
+                        vt[1][dt][0] = tr_read_asm_o<2048>(va + to.lo[dt]);
+                        vt[1][dt][1] = tr_read_asm_o<2048>(va + to.hi[dt]);
+                    }
                 }
                 f32x16 sc;
 #pragma unroll
@@ -380,47 +406,18 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__r
                     }
                     if (snext < nsuper) load_q(snext, qf);
                 }
-                float mx = sc[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                if (__any((mx - m) * c > 8.0f)) {     // lazy running maximum: attn_fwd_bf16_kernel
-                    const float mn = fmaxf(m, mx);
-                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-                    m = mn;
-                    l *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                }
-                const float mc = m * c;
-                float ls = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], c, -mc));
-                    sc[r] = p;
-                    ls += p;
-                }
-                l += ls;
                 u32x4 pk[2];
+                attn_fwd_tile_vec<DROP>(sc, m, l, o, c, (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix, c4, thi_mask, pk);
+                // the V^T fragments have landed (the wait names them: nothing that reads them may be scheduled above it)
+                if constexpr (VLATE) {
 #pragma unroll
-                for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(sc, ss));
-                if constexpr (DROP) {
-                    // dropout on the PACKED probabilities: per key quad (one hash word, 8 bits per key: the one-item kernel's mask bit for bit) the keep bits in
-                    // three bit-parallel instructions, per packed pair one byte permute + one packed arithmetic shift + one AND
-                    const uint32_t hb = (rowquad + (uint32_t)(kt * 8 + lh)) * ECGVIT_WEYL + smix;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t x = quad_keepbits(pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL), c4, t_hi);
-#pragma unroll
-                        for (int pp = 0; pp < 2; ++pp) {
-                            const uint32_t wv = __builtin_amdgcn_perm(x, x, pp ? 0x030C020Cu : 0x010C000Cu);
-                            pk[g >> 1][2 * (g & 1) + pp] &= __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2_t, wv) >> (s16x2_t){15, 15});
-                        }
+                    for (int dt = 0; dt < 2; ++dt) {
+                        vt[1][dt][0] = tr_read_asm_o<2048>(va + to.lo[dt]);
+                        vt[1][dt][1] = tr_read_asm_o<2048>(va + to.hi[dt]);
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                             "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]) :: "memory");
 #pragma unroll
                 for (int ss = 0; ss < 2; ++ss) {
                     const bf16x8 pf = __builtin_bit_cast(bf16x8, pk[ss]);
@@ -1352,8 +1349,10 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
     if (dropout_p > 0.f && dropout_threshold8(dropout_p) == 0) return ECGVIT_EINVAL;   // p < 1/512 would silently round to no dropout
     const uint32_t th = dropout_threshold8(dropout_p);
     const float ik = dropout_inv_keep8(dropout_p);
-    // the STREAMED form (one persistent 16-wave workgroup per CU, K / V windows through a two-slot ring) once there is a workgroup's worth of
-    // (record, head) items per CU; below that the one-item kernel, whose B*h workgroups spread over more CUs
+    // the STREAMED form (one persistent 16-wave workgroup per CU, K / V windows through a two-slot ring) for records of more than 256 tokens once there
+    // is an item per CU (256 x 16 x 501: 494 against 533 us, 8-bit emitting 523 against 575; profiles/r06_attn_fwd_stream.txt); below that the one-item
+    // kernel, whose B*h workgroups spread over more CUs.  Up to 256 tokens the one-item kernel stays (512 x 12 x 251: 215 against 236 us streamed -- with two
+    // items side by side a window is four key tiles, and the sixteen waves meet at a barrier every four tiles)
     {
         static int n_cu = 0;
         if (!n_cu) {
@@ -1362,7 +1361,7 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
             n_cu = v;
         }
         const int groups = N > 256 ? 1 : 2, nsuper = (B * h + groups - 1) / groups;
-        bool stream_form = nsuper >= n_cu && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
+        bool stream_form = N > 256 && nsuper >= n_cu && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
 #ifdef ECGVIT_TOOLS
         if (g_tools_attn_fwd_variant == 0) stream_form = false;
         if (g_tools_attn_fwd_variant == 1) stream_form = (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);

@@ -406,9 +406,10 @@ def test_attention_fwd_streamed_equals_one_item_kernel(B, h, N, p):
 
 
 def test_attention_fwd_product_dispatch_takes_the_streamed_kernel_at_full_occupancy():
-    """the product library picks the streamed forward once there is a workgroup's worth of items per CU (2 items per workgroup up to 256 tokens): at
-    600 x 1 x 251 / 300 x 1 x 501 it must agree with the double-precision reference like the one-item kernel does at the small shapes above"""
-    for B, h, N in ((600, 1, 251), (300, 1, 501)):
+    """the product library picks the streamed forward for records of more than 256 tokens once there is an item per CU: at 300 x 1 x 501 (and the
+    one-item kernel at 600 x 1 x 251) it must agree with the double-precision reference like the small shapes above (maximum error over 10 M bf16
+    outputs of magnitude ~1: 4e-2; relative error of the whole tensor as there)"""
+    for B, h, N in ((600, 1, 251), (300, 1, 501), (257, 2, 449)):
         g = torch.Generator().manual_seed(N)
         qkv = (torch.randn(B * N, 3 * 64, generator=g) * 1.5).to(BF16)
         out = torch.full((B * N, 64), float('nan'), device='cuda', dtype=BF16)
@@ -416,7 +417,7 @@ def test_attention_fwd_product_dispatch_takes_the_streamed_kernel_at_full_occupa
         check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, 64, 0.125, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
         o_ref, lse_ref, _ = _attn_ref(qkv.double(), B, N, h, 64, 0.125)
         assert torch.isfinite(out.float()).all()
-        assert max_err(out, o_ref) < 2e-2 and rel_err(out, o_ref) < 1e-2 and max_err(lse.view(B, h, N), lse_ref) < 2e-3
+        assert max_err(out, o_ref) < 4e-2 and rel_err(out, o_ref) < 1e-2 and max_err(lse.view(B, h, N), lse_ref) < 2e-3
 
 
 @pytest.mark.parametrize('N', [251, 501])
