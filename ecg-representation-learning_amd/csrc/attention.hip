@@ -66,6 +66,10 @@ __device__ __forceinline__ void attn_fwd_tile_vec(f32x16 &sc, float &m, float &l
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
+#ifndef ATTN_VEC_FORM
+#define ATTN_VEC_FORM 0   // 0 ships.  Measured at 256 x 16 x 501 (streamed kernel) / 512 x 12 x 251 (one-item kernel) against round 5 on one device (profiles/r06_attn_fwd_stream.txt): form 0 (scalar fma / exp / add, dropout as four selects per hash word) 476.7 / 198.3 us; 1 (dropout on the packed pairs: keep bits in three bit-parallel instructions, permute + packed shift + AND per pair) 485.6 / 201.3; 2 (1 + v_pk_fma_f32 / v_pk_add_f32 for the exponent argument and the row sum) 498.8 / 200.5 -- fewer instructions, slower: packed f32 forms issue at half rate beside the MFMAs (profiles/r04_valu_rate.txt) and the select form overlaps better
+#endif
+#if ATTN_VEC_FORM >= 2
     const f32x2 c2 = {c, c}, nmc = {-m * c, -m * c};
     f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
@@ -76,6 +80,29 @@ __device__ __forceinline__ void attn_fwd_tile_vec(f32x16 &sc, float &m, float &l
         ls2 += p;
     }
     l += ls2[0] + ls2[1];                           // per-half partial sums; halves are combined after the loop
+#else
+    const float mc = m * c;
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sc[r], c, -mc));   // one fma per score (the kernel is VALU-bound); argument <= 8
+        sc[r] = p;
+        ls += p;
+    }
+    l += ls;
+#endif
+#if ATTN_VEC_FORM == 0
+    if constexpr (DROP) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t hh = pair_finish(hb + (uint32_t)(2 * g) * ECGVIT_WEYL);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sc[4 * g + k] = ((hh >> (8 * k)) & 0xFFu) >= (256u - (c4 & 0xFFu) - 128u + (thi_mask & 128u)) ? sc[4 * g + k] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(sc, ss));
+#else
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) pk[ss] = __builtin_bit_cast(u32x4, pack8(sc, ss));
     if constexpr (DROP) {  // dropout on the probabilities (the normaliser keeps the un-dropped sum: softmax -> Dropout); the 1/(1-p) rescale is folded
@@ -92,6 +119,7 @@ __device__ __forceinline__ void attn_fwd_tile_vec(f32x16 &sc, float &m, float &l
             }
         }
     }
+#endif
 }
 
 template <bool DROP, bool Q8 = false, bool SPLIT = false>

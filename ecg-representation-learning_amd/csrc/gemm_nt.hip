@@ -42,6 +42,14 @@ using nt_tiles::xcd_remap;
 using nt_tiles::decode_tile;
 
 #define NT_HAS(f) (((FL >= 0) ? FL : e.flags) & (f))
+// PRICING EXPERIMENT (round 6, tools build only; a template flag, never a descriptor flag): LayerNorm folded into its consumer product --
+// LN(x) . W^T = rstd[m] (x . (gamma o W)^T)[m, n] - (rstd mu)[m] ((gamma o W) . 1)[n] + (W . beta)[n], i.e. per output element two FMAs on a row pair
+// (a[m], b[m]) and a column vector g[n] (the second column vector rides on the bias).  tools/gemm_ab.py --rowaffine times the QKV forward and the FFN-up
+// forward with it against what ships; nothing in the product instantiates it.  profiles/r06_ln_fold_pricing.txt
+#define ECGVIT_EPI_ROWAFFINE_X 4096
+#ifdef ECGVIT_TOOLS
+__device__ const float *g_ra_a = nullptr, *g_ra_b = nullptr, *g_ra_g = nullptr;   // row vectors [M], column vector [N] (ecgvit_tools_rowaffine)
+#endif
 
 // two f32 -> one dword of two bf16 (RNE, NaN-safe); written out because hipcc otherwise pairs the converts of an 8-element
 // run across odd register boundaries (5 converts + 4 v_perm/v_alignbit per 16-B store instead of 4 converts)
@@ -126,7 +134,7 @@ __device__ __forceinline__ void nt_epi8(float (&v)[8], const float *bias8, uint3
             for (int k = 0; k < 8; ++k) v[k] *= e.alpha;
         }
     }
-    if (NT_HAS(ECGVIT_EPI_BIAS)) {
+    if (NT_HAS(ECGVIT_EPI_BIAS) && !(kLightBody && (FL & ECGVIT_EPI_ROWAFFINE_X))) {   // (the light row-affine pricing body has folded the bias into its second FMA)
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] += bias8[k];
     }
@@ -297,6 +305,18 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll
         for (int k = 0; k < 16; ++k) bias[k] = 0.f;
     }
+    constexpr bool kRA = FL >= 0 && (FL & ECGVIT_EPI_ROWAFFINE_X) != 0;
+    [[maybe_unused]] float rag[16];
+    [[maybe_unused]] const float *ra_a = nullptr, *ra_b = nullptr;
+#ifdef ECGVIT_TOOLS
+    if constexpr (kRA) {
+        ra_a = g_ra_a; ra_b = g_ra_b;
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(g_ra_g + nl0), g1 = *reinterpret_cast<const f32x4 *>(g_ra_g + nl0 + 4);
+        const f32x4 g2 = *reinterpret_cast<const f32x4 *>(g_ra_g + nl1), g3 = *reinterpret_cast<const f32x4 *>(g_ra_g + nl1 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rag[k] = g0[k]; rag[4 + k] = g1[k]; rag[8 + k] = g2[k]; rag[12 + k] = g3[k]; }
+    }
+#endif
     float cs[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) cs[k] = 0.f;
@@ -349,6 +369,11 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         // light bodies: every row load of the tile is issued up front (the 64 fragment registers are free now), then the 8 row steps
         // run fully unrolled on the accumulators in place; stores are fire-and-forget
         u32x4 R[8][2], X[8][2];
+        [[maybe_unused]] float RA[8], RB[8];
+        if constexpr (kRA) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const int mc = min((int)mrow + 16 * i, M - 1); RA[i] = ra_a[mc]; RB[i] = ra_b[mc]; }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -364,6 +389,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
             float v0[8], v1[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v0[r] = acc[i][0][r]; v0[4 + r] = acc[i][1][r]; v1[r] = acc[i][2][r]; v1[4 + r] = acc[i][3][r]; }
+            if constexpr (kRA) {   // two FMAs per element: v rstd[m] + ((rstd mu)[m] g[n] + c[n]) (c = the bias vector)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v0[k] = fmaf(v0[k], RA[i], fmaf(RB[i], rag[k], bias[k])); v1[k] = fmaf(v1[k], RA[i], fmaf(RB[i], rag[8 + k], bias[8 + k])); }
+            }
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
             nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(R[i][0], want_res), to_acc_aux(X[i][0], want_aux), cs, qmax);
@@ -374,6 +403,8 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         // heavy bodies must exist ONCE in the instruction stream (I-cache): rolled loop, only the accumulator pick is a switch;
         // row loads one step ahead
         u32x4 nr0 = ld_res(0, 0), nr1 = ld_res(0, 1), na0 = ld_aux(0, 0), na1 = ld_aux(0, 1);
+        [[maybe_unused]] float nra = 0.f, nrb = 0.f;
+        if constexpr (kRA) { const int mc = min((int)mrow, M - 1); nra = ra_a[mc]; nrb = ra_b[mc]; }
         // hipcc's wait-count model does not see LDS-DMA: behind the pieces it would wait `vmcnt(0)` for the bias (all of it is needed by
         // the first row), i.e. for the pieces too.  Consume the bias here, while only the epilogue's own loads are in flight
         if (NT_HAS(ECGVIT_EPI_BIAS)) {
@@ -385,7 +416,9 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
 #pragma unroll 1
         for (int i = 0; i < 8; ++i) {
             const u32x4 r0 = nr0, r1 = nr1, a0 = na0, a1 = na1;
+            [[maybe_unused]] const float cra = nra, crb = nrb;
             if (i < 7) { nr0 = ld_res(i + 1, 0); nr1 = ld_res(i + 1, 1); na0 = ld_aux(i + 1, 0); na1 = ld_aux(i + 1, 1); }
+            if constexpr (kRA) { if (i < 7) { const int mc = min((int)mrow + 16 * (i + 1), M - 1); nra = ra_a[mc]; nrb = ra_b[mc]; } }
             float v0[8], v1[8];
 #define NT_PICK(I)                                                                                       \
     case I:                                                                                              \
@@ -395,6 +428,10 @@ __device__ __forceinline__ void nt_epilogue(f32x4 (&acc)[8][4], const ecgvit_gem
         break;
             switch (i) { NT_PICK(0) NT_PICK(1) NT_PICK(2) NT_PICK(3) NT_PICK(4) NT_PICK(5) NT_PICK(6) default: NT_PICK(7) }
 #undef NT_PICK
+            if constexpr (kRA) {   // (the bias add stays where it is in the heavy body: here fma + multiply = the same two instructions per element)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v0[k] = fmaf(v0[k], cra, crb * rag[k]); v1[k] = fmaf(v1[k], cra, crb * rag[8 + k]); }
+            }
             const uint32_t m = mrow + 16 * i, mm = mrowm + 16 * i;
             const bool mok = (int)m < M, mokm = (int)mm < M;
             nt_epi8<TO, FL, CAUX>(v0, bias, m, nb, mok && nok0, mm, nbm, mokm && nokm0, bf, e, to_acc(r0, want_res), to_acc_aux(a0, want_aux), cs, qmax);
@@ -1120,6 +1157,14 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #endif
 #define NT_LAUNCH8(FL, OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, FL, false, OPS>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
 #ifdef ECGVIT_TOOLS
+    if ((diag & 1024) && d->dtype == ECGVIT_BF16 && d->out_dtype == ECGVIT_BF16) {   // LayerNorm-fold pricing (ECGVIT_EPI_ROWAFFINE_X): QKV forward / FFN-up forward bodies
+        constexpr int RA = ECGVIT_EPI_ROWAFFINE_X;
+        if (fl == ECGVIT_EPI_BIAS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, ECGVIT_EPI_BIAS | RA, false, 0, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0);
+        else if (fl == (F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8)) NT_LAUNCH(bf16_t, F_UP | ECGVIT_EPI_DROPOUT | ECGVIT_EPI_AUX8 | RA);
+        else return ECGVIT_EINVAL;
+        ECGVIT_CHECK_LAUNCH();
+        return ECGVIT_OK;
+    }
     if ((diag & 64) && fl == 0 && d->dtype == ECGVIT_FP8_E4M3) { NT_LAUNCH8(0, 1); ECGVIT_CHECK_LAUNCH(); return ECGVIT_OK; }   // plain fp8 MFMA (A/B)
 #endif
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
@@ -1251,6 +1296,10 @@ int ecgvit_gemm_nt4w_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster
 }
 
 #ifdef ECGVIT_TOOLS
+extern "C" int ecgvit_tools_rowaffine(const float *row_a, const float *row_b, const float *col_g) {   // operands of the LayerNorm-fold pricing bodies
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_ra_a), &row_a, sizeof(row_a)) == hipSuccess && hipMemcpyToSymbol(HIP_SYMBOL(g_ra_b), &row_b, sizeof(row_b)) == hipSuccess &&
+            hipMemcpyToSymbol(HIP_SYMBOL(g_ra_g), &col_g, sizeof(col_g)) == hipSuccess) ? ECGVIT_OK : ECGVIT_ELAUNCH;
+}
 // stand-in for a collective's kernel: n workgroups that each hold a whole CU (all of its LDS) for `cycles` shader cycles
 __global__ __launch_bounds__(64) void tools_occupy_kernel(unsigned long long cycles, unsigned int *done) {
     __shared__ char hold[LDS_BYTES];

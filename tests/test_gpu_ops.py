@@ -411,8 +411,8 @@ def test_attention_fwd_product_dispatch_takes_the_streamed_kernel_at_full_occupa
     outputs of magnitude ~1: 4e-2; relative error of the whole tensor as there)"""
     for B, h, N in ((600, 1, 251), (300, 1, 501), (257, 2, 449)):
         g = torch.Generator().manual_seed(N)
-        qkv = (torch.randn(B * N, 3 * 64, generator=g) * 1.5).to(BF16)
-        out = torch.full((B * N, 64), float('nan'), device='cuda', dtype=BF16)
+        qkv = (torch.randn(B * N, 3 * h * 64, generator=g) * 1.5).to(BF16)
+        out = torch.full((B * N, h * 64), float('nan'), device='cuda', dtype=BF16)
         lse = torch.zeros(B * h * N, device='cuda')
         check(lib().ecgvit_attention_fwd(ptr(dev(qkv)), ptr(out), ptr(lse), B, N, h, 64, 0.125, 0.0, 0, hip.BF16, stream()), 'attn_fwd')
         o_ref, lse_ref, _ = _attn_ref(qkv.double(), B, N, h, 64, 0.125)

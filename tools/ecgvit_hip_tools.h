@@ -29,6 +29,9 @@ int ecgvit_debug_attn_stamps(void *buf);
 
 /* GEMM A/B and stamps (tools/gemm_ab.py, tools/nt_stamps.py, tools/contention.py, tools/wgrad_ab.py) */
 int ecgvit_tools_gemm(const ecgvit_gemm_desc *d, void *stream, int kernel, int raster_g, int diag);
+/* LayerNorm-fold pricing (round 6; diag bit 1024 of ecgvit_tools_gemm, kernel 2): the QKV-forward (epilogue BIAS, non-temporal stores) and FFN-up-forward
+ * bodies with v = v a[m] + (b[m] g[n] + bias[n]) in front of their epilogue; a, b: f32 [M]; g: f32 [N] */
+int ecgvit_tools_rowaffine(const float *row_a, const float *row_b, const float *col_g);
 int ecgvit_tools_occupy(int n_cus, unsigned long long cycles, unsigned int *done, void *stream);
 int ecgvit_tools_nt_stamps(unsigned long long *h_out);
 void ecgvit_tools_wgrad_body(int eight_wave);

@@ -43,6 +43,8 @@ def main():
     ap.add_argument('--aux8', action='store_true', help='the FFN-wide epilogues with the e4m3 saved tensor (ECGVIT_EPI_AUX8)')
     ap.add_argument('--rdv', action='store_true', help='experiment: the stamped eight-wave instantiation without / with the XCD rendezvous per tile round (plain, FFN-up, x-aux cases)')
     ap.add_argument('--nt4', action='store_true', help='also time the four-wave body (kernel 3) on every plain product')
+    ap.add_argument('--rowaffine', action='store_true', help='LayerNorm-fold pricing (round 6): the QKV forward and (with --aux8) the FFN-up forward with the row-affine epilogue '
+                    'v a[m] + (b[m] g[n] + c[n]) of LN folded into its consumer product, next to what ships, and the LayerNorm forward pass each would replace')
     args = ap.parse_args()
     lib = hip.lib()
     tg = lib.ecgvit_tools_gemm
@@ -63,6 +65,30 @@ def main():
     dev = 'cuda'
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
     results = []
+    if args.rowaffine:
+        ra = lib.ecgvit_tools_rowaffine
+        ra.restype, ra.argtypes = ctypes.c_int, [ctypes.c_void_p] * 3
+        torch.manual_seed(2)
+        row_a, row_b = torch.rand(M, device=dev) + 0.5, torch.randn(M, device=dev) * 0.1
+        col_g = torch.randn(max(3 * d, f), device=dev)
+        assert ra(row_a.data_ptr(), row_b.data_ptr(), col_g.data_ptr()) == 0
+        # the pass the fold would delete: LayerNorm forward over [M, d] bf16 (writes xn, mean, rstd)
+        x = torch.randn(M, d, device=dev).to(bf)
+        y = torch.empty_like(x)
+        gam, bet = torch.ones(d, device=dev), torch.zeros(d, device=dev)
+        mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+        st0 = torch.cuda.current_stream().cuda_stream
+        ts = []
+        for _ in range(args.rounds + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                lib.ecgvit_layernorm_fwd(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), M, d, 1e-5, hip.BF16, st0)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / args.iters * 1e3)
+        ts = sorted(ts[1:])
+        print(f'layernorm_fwd [{M} x {d}] bf16 (the pass a fold deletes, once per consumer): median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us', flush=True)
     for name, K, N, epi in cases:
         torch.manual_seed(1)
         X = torch.randn(M, K, device=dev).to(bf)
@@ -96,9 +122,15 @@ def main():
             variants.append(('4w nt', 3, 0, 2))
         if args.nt4 and epi in (LIN, DH):
             variants.append(('4w', 3, 0, 0))
+        fold = None
+        if args.rowaffine and (name == 'fwd qkv' or (name == 'fwd ffn_up' and args.aux8)):
+            fold = ('8w nt + LN fold' if epi == 0 else 'shipped + LN fold', 2, 0, 1024)
+            variants.append(fold)
         C = {v[0]: torch.empty(M, N, device=dev, dtype=bf) for v in variants}
         A = {v[0]: (aux.clone() if aux is not None else None) for v in variants}
         descs = {v[0]: make(C[v[0]], A[v[0]]) for v in variants}
+        if fold is not None and epi == 0:   # the QKV forward's fold body takes its second column vector through the bias
+            descs[fold[0]] = hip.gemm_desc(GEMM_NT, X, W, C[fold[0]], M, N, K, K, K, N, epilogue=EPI_BIAS, bias=bias, workspace=ws)
         st = torch.cuda.current_stream().cuda_stream
 
         def run(v):
@@ -131,6 +163,14 @@ def main():
             print(f'{name:15s} K={K:4d} N={N:4d} epi={epi:3d}  {n:16s}: median {med:7.1f} us  min {mn:7.1f} us  {fl / med / 1e6:7.1f} TFLOP/s '
                   f'({100 * fl / med / 1e6 / 2500:4.1f} %)', flush=True)
             results.append(dict(case=name, K=K, N=N, epilogue=epi, variant=n, median_us=med, min_us=mn, tflops=fl / med / 1e6))
+        if fold is not None and args.check:
+            # the fold body against the same transform applied to the shipped body's output path: v a + (b g + c) on the f32 product of a row sample
+            rows = torch.randint(0, M, (256,), device=dev)
+            acc = X[rows].float() @ W.float().t()
+            if epi == 0:
+                want = acc * row_a[rows, None] + (row_b[rows, None] * col_g[None, :N] + bias[None, :])
+                err = (C[fold[0]][rows].float() - want).abs().max().item()
+                print(f'   check {fold[0]} vs f32 reference (256 rows): max abs err {err:.3e} (|want| max {want.abs().max().item():.2f})', flush=True)
         if args.check and len(variants) >= 2:
             ref = C[variants[0][0]].float()
             for v in variants[1:]:
