@@ -314,14 +314,18 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_bf16_kernel(const bf16_t *__r
 // sixteen waves idle: profiles/r05_attn_ablation.txt).  V^T fragments are inline-asm transposed reads (hipcc drains vmcnt(0) in front of the builtin
 // form when an LDS-DMA is in flight: attn_common.h), requested at the top of a tile and consumed behind its softmax.
 // =====================================================================================================
-template <bool DROP, bool Q8, int GROUPS>
-__global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, float *__restrict__ lse, int N, int h,
+// MODE 1: 16 waves, one item, 256-key windows (N > 256).  MODE 2: 16 waves, two items side by side, 128-key windows (N <= 256).  MODE 3: 8 waves, one item,
+// 128-key windows, TWO workgroups per CU with a 2 x 32 KiB ring each (N <= 256): a workgroup's barrier joins its own eight waves only
+template <bool DROP, bool Q8, int MODE>
+__global__ __launch_bounds__(MODE == 3 ? 512 : 1024, 4) void attn_fwd_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ out, float *__restrict__ lse, int N, int h,
                                                                float scale, uint64_t seed, uint32_t thresh, float inv_keep, int nitems,
                                                                uint8_t *__restrict__ out8 = nullptr, const float *__restrict__ q8_scale = nullptr,
                                                                float *__restrict__ q8_amax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 slots x 64 KiB
-    constexpr int WG_ = 16 / GROUPS;      // waves = 32-query blocks per item
-    constexpr int WK = 256 / GROUPS;      // keys per window
+    constexpr int GROUPS = MODE == 2 ? 2 : 1, NWV = MODE == 3 ? 8 : 16;
+    constexpr int WG_ = NWV / GROUPS;     // waves = 32-query blocks per item
+    constexpr int WK = MODE == 1 ? 256 : 128;   // keys per window
+    constexpr int SLOT = GROUPS * WK * 256;     // bytes of a ring slot
     constexpr int TPW = WK / 32;          // key tiles per window
     constexpr int GB = WK * 256;          // bytes of one group's K + V images inside a slot
     constexpr int NST = Q8 ? 7 : 5;       // vector-memory operations a wave issues behind its Q request: 4 output stores of 16 B (+ 2 of the 8-bit copy) + the LSE store
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__r
         const int b = item / h, hd = item - b * h;
         const bf16_t *base = qkv + (int64_t)b * N * d3 + hd * 64;
         const int k0 = w * WK, nv = min(WK, N - k0), rp = ((nv + 31) >> 5) << 5;
-        char *Kimg = smem + slot * 65536 + group * GB;
+        char *Kimg = smem + slot * SLOT + group * GB;
         dma_image<WG_>(Kimg, base + d + (int64_t)k0 * d3, d3, nv, rp, wq, lane);
         dma_image<WG_>(Kimg + WK * 128, base + 2 * d + (int64_t)k0 * d3, d3, nv, rp, wq, lane);
     };
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_stream_kernel(const bf16_t *__r
             if (w + 1 < nw) issue(s, w + 1, (t + 1) & 1);
             else if (snext < nsuper) issue(snext, 0, (t + 1) & 1);
             if (!live) continue;
-            const char *Kimg = smem + (t & 1) * 65536 + group * GB, *Vimg = Kimg + WK * 128;
+            const char *Kimg = smem + (t & 1) * SLOT + group * GB, *Vimg = Kimg + WK * 128;
             const int ntile = min(TPW, nkt - w * TPW);
             for (int ktl = 0; ktl < ntile; ++ktl) {
                 const int kt = w * TPW + ktl;
@@ -779,21 +783,14 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     const TrOff to = make_tr_off(lane);
     const int dq_g = lane >> 4, dq_i = lane & 15;
     const int dq_key = 4 * dq_g + (dq_i >> 2);
-    const int dq_a[2] = {dq_key * 64 + (((0 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3), dq_key * 64 + (((1 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3)};
-    int dq_b[4];
-#pragma unroll
-    for (int dhc = 0; dhc < 4; ++dhc) dq_b[dhc] = img_off(dq_key, (dhc * 16 + (dq_i & 3) * 4) * 2);
+    // this wave's dQ tile is fixed (qt = wave & 1, dhc = wave >> 1): ONE offset of each image instead of tables indexed by a uniform (six registers)
+    const int dq_aoff = dq_key * 64 + ((((wave & 1) * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3);
+    const int dq_boff = img_off(dq_key, ((wave >> 1) * 16 + (dq_i & 3) * 4) * 2);
 
     // per-lane DMA source offsets (bytes): a piece = 8 image rows; the image swizzle is applied to the SOURCE chunk
     const int prow = (wave & 3) * 8 + (lane >> 3);                          // slab piece row (0..31)
     const int pchunk = ((lane & 7) ^ swz3(prow)) * 16;
     const int vo_q = prow * d3 * 2 + pchunk, vo_d = prow * d * 2 + pchunk;  // Q (row pitch 3d) ; dO / O (row pitch d)
-    int vo_k[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave + 8 * i) * 8 + (lane >> 3);
-        vo_k[i] = row * d3 * 2 + (((lane & 7) ^ swz3(row)) * 16);
-    }
     const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_d = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
     const uint32_t bytes_k = (uint32_t)(((int64_t)(N - k0 - 1) * d3 + 64) * 2);   // K / V / dK / dV rows of this launch's key window (keys >= N: out of bounds)
 
@@ -821,8 +818,15 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     };
     auto dma_k = [&](const Item &x, char *img) {
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + d + (int64_t)k0 * d3), 0, bytes_k, 0x00020000);
+        // the four source offsets are recomputed here, once per item, from a lane id the compiler cannot see through: kept as loop invariants they
+        // hold four registers through the whole main loop (what the staggered second-window emitting instantiation was short of: round 6)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, vo_k[i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave + 8 * i) * 8 + (ln >> 3);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, row * d3 * 2 + (((ln & 7) ^ swz3(row)) * 16), 0, 0, 0);
+        }
     };
     // Every global access below is a bounds-checked BUFFER operation on a per-item descriptor (rows >= N read zero / are dropped by
     // the hardware): no lane predicate, so each wave issues the same number of memory instructions whatever N is -- the counted
@@ -1095,7 +1099,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             const char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
             const int qt = wave & 1, dhc = wave >> 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int aoff = dq_a[qt], boff = dq_b[dhc];
+            const int aoff = dq_aoff, boff = dq_boff;
             const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
             // the four key-step groups are software-pipelined by one: group h+1's eight transposed reads are in flight while group h's two
             // MFMAs run (counted lgkmcnt; after the barrier 48+ registers of the block's arithmetic are dead): one exposed LDS round trip
@@ -1388,11 +1392,15 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return ECGVIT_ELAUNCH;
             n_cu = v;
         }
-        const int groups = N > 256 ? 1 : 2, nsuper = (B * h + groups - 1) / groups;
+        int mode = N > 256 ? 1 : 2;
+#ifdef ECGVIT_TOOLS
+        if (g_tools_attn_fwd_variant == 2 && N <= 256) mode = 3;
+#endif
+        const int groups = mode == 2 ? 2 : 1, nsuper = (B * h + groups - 1) / groups;
         bool stream_form = N > 256 && nsuper >= n_cu && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
 #ifdef ECGVIT_TOOLS
         if (g_tools_attn_fwd_variant == 0) stream_form = false;
-        if (g_tools_attn_fwd_variant == 1) stream_form = (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
+        if (g_tools_attn_fwd_variant >= 1) stream_form = (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
 #endif
         if (stream_form) {
             static bool sattr = false;
@@ -1400,12 +1408,15 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
 #define SATTR(DR, Q, G) if (hipFuncSetAttribute((const void *)attn_fwd_stream_kernel<DR, Q, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ECGVIT_ELAUNCH
                 SATTR(true, false, 1); SATTR(false, false, 1); SATTR(true, true, 1); SATTR(false, true, 1);
                 SATTR(true, false, 2); SATTR(false, false, 2); SATTR(true, true, 2); SATTR(false, true, 2);
+                SATTR(true, false, 3); SATTR(false, false, 3); SATTR(true, true, 3); SATTR(false, true, 3);
 #undef SATTR
                 sattr = true;
             }
-            const dim3 sg((unsigned)(nsuper < n_cu ? nsuper : n_cu));
-#define SFWD(DR, Q, G) hipLaunchKernelGGL((attn_fwd_stream_kernel<DR, Q, G>), sg, dim3(1024), 128 * 1024, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, B * h, (uint8_t *)out8, q8_scale, q8_amax)
-#define SFWD2(DR, Q) do { if (groups == 1) SFWD(DR, Q, 1); else SFWD(DR, Q, 2); } while (0)
+            const int slots = mode == 3 ? 2 * n_cu : n_cu;
+            const dim3 sg((unsigned)(nsuper < slots ? nsuper : slots)), sb(mode == 3 ? 512 : 1024);
+            const size_t slds = mode == 3 ? 64 * 1024 : 128 * 1024;
+#define SFWD(DR, Q, G) hipLaunchKernelGGL((attn_fwd_stream_kernel<DR, Q, G>), sg, sb, slds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, B * h, (uint8_t *)out8, q8_scale, q8_amax)
+#define SFWD2(DR, Q) do { if (mode == 1) SFWD(DR, Q, 1); else if (mode == 2) SFWD(DR, Q, 2); else SFWD(DR, Q, 3); } while (0)
             if (out8) { if (th) SFWD2(true, true); else SFWD2(false, true); }
             else { if (th) SFWD2(true, false); else SFWD2(false, false); }
 #undef SFWD2
@@ -1495,7 +1506,8 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
 #define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER, ATTN_BWD_PRIO>), PERS_ARGS(K0))
 // (the emitting variants run the staggered schedule as well since round 4's vector diet -- 239-255 VGPRs, no spills -- except the second key
 // window under dropout with all three conversions, which would spill 4 registers: scratch traffic would join the counted vmcnt waits, so that
-// one keeps the lockstep schedule)
+// one keeps the lockstep schedule; round 6 took ten loop-invariant registers out of the kernel -- the K-image offsets, the dQ offset tables -- and it
+// still spills those four: the peak is inside the block's vector phase, not in what lives across it)
 #define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER && !(DR && AC && Q == 3), ATTN_BWD_PRIO, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
     if (g_tools_attn_variant >= 0 && th && N <= 256 && !dqkv8) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)

@@ -36,7 +36,8 @@ def main():
     sc = torch.full((1,), 0.01, device='cuda')
     amax = torch.zeros(1, device='cuda')
     bufs = {}
-    for v in (0, 1):
+    VS = (0, 1, 2) if N <= 256 else (0, 1)   # 2: the 8-wave streamed form, two workgroups per CU (N <= 256 only)
+    for v in VS:
         bufs[v] = (torch.empty(B * N, d, device='cuda', dtype=bf), torch.empty(B * h * N, device='cuda'), torch.empty(B * N, d, device='cuda', dtype=torch.uint8))
 
     def run(v, q8):
@@ -48,14 +49,14 @@ def main():
             rc = tl.ecgvit_attention_fwd(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, h, dh, 0.125, a.p, 7, hip.BF16, st)
         assert rc == 0, rc
     for q8 in (False, True):
-        for v in (0, 1):
+        for v in VS:
             run(v, q8)
         torch.cuda.synchronize()
-        same = all(torch.equal(bufs[0][i].view(torch.uint8), bufs[1][i].view(torch.uint8)) for i in ((0, 1, 2) if q8 else (0, 1)))
+        same = all(torch.equal(bufs[0][i].view(torch.uint8), bufs[v][i].view(torch.uint8)) for v in VS[1:] for i in ((0, 1, 2) if q8 else (0, 1)))
         print(f'{B} x {h} x {N}, p = {a.p}, {"8-bit emitting" if q8 else "plain"}: one-item vs streamed outputs {"bit-identical" if same else "DIFFERENT"}')
-        t = {0: [], 1: []}
+        t = {v: [] for v in VS}
         for _ in range(a.rounds):
-            for v in (0, 1):
+            for v in VS:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
@@ -63,7 +64,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 t[v].append(1e3 * e0.elapsed_time(e1) / a.iters)
-        for v, nm in ((0, 'one item per workgroup'), (1, 'streamed (persistent, 16 waves)')):
+        for v, nm in ((0, 'one item per workgroup'), (1, 'streamed (persistent, 16 waves)'), (2, 'streamed (8 waves, 2 wg / CU)'))[:len(VS)]:
             x = sorted(t[v][1:])
             print(f'   {nm:34s} median {x[len(x) // 2]:7.1f} us  min {x[0]:7.1f} us')
     tl.ecgvit_tools_attn_fwd_variant(-1)
