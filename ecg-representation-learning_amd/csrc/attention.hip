@@ -783,14 +783,21 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     const TrOff to = make_tr_off(lane);
     const int dq_g = lane >> 4, dq_i = lane & 15;
     const int dq_key = 4 * dq_g + (dq_i >> 2);
-    // this wave's dQ tile is fixed (qt = wave & 1, dhc = wave >> 1): ONE offset of each image instead of tables indexed by a uniform (six registers)
-    const int dq_aoff = dq_key * 64 + ((((wave & 1) * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3);
-    const int dq_boff = img_off(dq_key, ((wave >> 1) * 16 + (dq_i & 3) * 4) * 2);
+    const int dq_a[2] = {dq_key * 64 + (((0 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3), dq_key * 64 + (((1 * 4 + (dq_i & 3)) ^ dsw(dq_key)) << 3)};
+    int dq_b[4];
+#pragma unroll
+    for (int dhc = 0; dhc < 4; ++dhc) dq_b[dhc] = img_off(dq_key, (dhc * 16 + (dq_i & 3) * 4) * 2);
 
     // per-lane DMA source offsets (bytes): a piece = 8 image rows; the image swizzle is applied to the SOURCE chunk
     const int prow = (wave & 3) * 8 + (lane >> 3);                          // slab piece row (0..31)
     const int pchunk = ((lane & 7) ^ swz3(prow)) * 16;
     const int vo_q = prow * d3 * 2 + pchunk, vo_d = prow * d * 2 + pchunk;  // Q (row pitch 3d) ; dO / O (row pitch d)
+    int vo_k[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave + 8 * i) * 8 + (lane >> 3);
+        vo_k[i] = row * d3 * 2 + (((lane & 7) ^ swz3(row)) * 16);
+    }
     const uint32_t bytes_q = (uint32_t)(((int64_t)(N - 1) * d3 + 64) * 2), bytes_d = (uint32_t)(((int64_t)(N - 1) * d + 64) * 2);
     const uint32_t bytes_k = (uint32_t)(((int64_t)(N - k0 - 1) * d3 + 64) * 2);   // K / V / dK / dV rows of this launch's key window (keys >= N: out of bounds)
 
@@ -818,15 +825,8 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     };
     auto dma_k = [&](const Item &x, char *img) {
         const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(x.q + d + (int64_t)k0 * d3), 0, bytes_k, 0x00020000);
-        // the four source offsets are recomputed here, once per item, from a lane id the compiler cannot see through: kept as loop invariants they
-        // hold four registers through the whole main loop (what the staggered second-window emitting instantiation was short of: round 6)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (wave + 8 * i) * 8 + (ln >> 3);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, row * d3 * 2 + (((ln & 7) ^ swz3(row)) * 16), 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void_p)(img + (wave + 8 * i) * 1024), 16, vo_k[i], 0, 0, 0);
     };
     // Every global access below is a bounds-checked BUFFER operation on a per-item descriptor (rows >= N read zero / are dropped by
     // the hardware): no lane predicate, so each wave issues the same number of memory instructions whatever N is -- the counted
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
             const char *dsb = dSimg + ((jj0 + qb) & 1) * DSB;
             const int qt = wave & 1, dhc = wave >> 1;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int aoff = dq_aoff, boff = dq_boff;
+            const int aoff = dq_a[qt], boff = dq_b[dhc];
             const uint32_t sa = lds_addr_of(dsb) + aoff, ka = lds_addr_of(Kimg) + boff;
             // the four key-step groups are software-pipelined by one: group h+1's eight transposed reads are in flight while group h's two
             // MFMAs run (counted lgkmcnt; after the barrier 48+ registers of the block's arithmetic are dead): one exposed LDS round trip
@@ -1506,8 +1506,9 @@ static int attention_bwd_launch(const void *qkv, const void *out, const void *do
 #define PERS(DR, AC, K0) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER, ATTN_BWD_PRIO>), PERS_ARGS(K0))
 // (the emitting variants run the staggered schedule as well since round 4's vector diet -- 239-255 VGPRs, no spills -- except the second key
 // window under dropout with all three conversions, which would spill 4 registers: scratch traffic would join the counted vmcnt waits, so that
-// one keeps the lockstep schedule; round 6 took ten loop-invariant registers out of the kernel -- the K-image offsets, the dQ offset tables -- and it
-// still spills those four: the peak is inside the block's vector phase, not in what lives across it)
+// one keeps the lockstep schedule; round 6 took ten loop-invariant registers out of the kernel -- the K-image offsets recomputed per item, the dQ offset
+// tables replaced by the wave's one offset -- and it still spilled those four (the peak is inside the block's vector phase, not in what lives across it),
+// while the other instantiations got 1.6-2 % SLOWER with the different allocation: taken out again)
 #define PERS8(DR, AC, K0, Q) hipLaunchKernelGGL((attn_bwd_pers_kernel<DR, AC, ATTN_BWD_STAGGER && !(DR && AC && Q == 3), ATTN_BWD_PRIO, Q>), PERS_ARGS(K0), (uint8_t *)dqkv8, q8_scale, q8_amax)
 #ifdef ECGVIT_TOOLS
     if (g_tools_attn_variant >= 0 && th && N <= 256 && !dqkv8) {   // tools build: A/B of the stagger / priority variants (tools/attn_variants.py)

@@ -526,8 +526,8 @@ def test_training_scales_survive_an_eval_pass():
     eval activations carry no 1 / (1 - p) rescale, scales have no headroom, and the FFN hidden activation would saturate in e4m3 for that step.
     The engine keeps the last training pass's scales there (and discards the eval pass's amax)."""
     from oracle import vit_oracle as O
-    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
-                          hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5)   # p = 0.5: training activations are 2 x the eval ones
+    conf = E.EcgVitConfig(max_signal_length=5000, patch_size=20, hidden_size=512, num_hidden_layers=2, num_attention_heads=8, intermediate_size=2048,
+                          hidden_dropout_prob=0.5, attention_probs_dropout_prob=0.5)   # p = 0.5: training activations are 2 x the eval ones (the 8-bit kernel wants K >= 384)
     torch.manual_seed(8)
     m = E.EcgVit(config=conf, compute_dtype=BF16, fp8_linear=True).cuda().train()
     x, y = O.synthetic_batch(12, length=5000, seed=8)
