@@ -628,11 +628,13 @@ def test_activation_pool_survives_crossing_the_e4m3_saved_tensor_boundary():
     assert eng._aux8(45 * eng.N) and eng.act['layers'][0]['hpre'].dtype == torch.uint8
     l45, g45 = float(big.loss.detach()), m._gflat.clone()
     base = {k: v.data_ptr() for k, v in eng._pool.items()}
+    m.zero_grad(set_to_none=True)                                                  # (loss.backward() ACCUMULATES into .grad like any module)
     small = m(sample_values=xc[:8].contiguous(), labels=yc[:8].contiguous())      # 408 rows: the bf16 saved tensor, on the small kernels
     small.loss.backward()
     assert not eng._aux8(8 * eng.N) and eng.act['layers'][0]['hpre'].dtype == BF16 and eng.act['layers'][0]['hpre'].shape == (8 * eng.N, 384)
     assert {k: v.data_ptr() for k, v in eng._pool.items()} == base
     l8, g8 = float(small.loss.detach()), m._gflat.clone()
+    m.zero_grad(set_to_none=True)
     again = m(sample_values=xc, labels=yc)
     again.loss.backward()
     assert {k: v.data_ptr() for k, v in eng._pool.items()} == base and eng.act['layers'][0]['hpre'].dtype == torch.uint8
