@@ -1167,9 +1167,19 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     }
     if ((diag & 64) && fl == 0 && d->dtype == ECGVIT_FP8_E4M3) { NT_LAUNCH8(0, 1); ECGVIT_CHECK_LAUNCH(); return ECGVIT_OK; }   // plain fp8 MFMA (A/B)
 #endif
+    // plain 8-bit products whose bf16 output does not fit the 256-MB Infinity Cache (EcgVit-large: the QKV forward's 788 MB) store it non-temporally, as
+    // the bf16 QKV forward does since round 3: written through L2 the output evicts the operand panels the tile's neighbours are about to re-read
+    // (tools/fp8_nt_ab.py at 256 x 501 token rows, default -> non-temporal: QKV forward K = 1024, 752 MB: 403.8 -> 350.5 us; the 250-MB outputs: K = 1024
+    // 145.5 -> 133.8, K = 3072 323.0 -> 338.1, K = 4096 411.8 -> 422.9: a long main loop re-reads its panels from L2 often enough to want the cache's help)
+    [[maybe_unused]] bool nt8 = (int64_t)d->M * d->N * 2 > (320ll << 20) || ((int64_t)d->M * d->N * 2 > (240ll << 20) && d->K <= 1024);
+#ifdef ECGVIT_TOOLS
+    if (diag & 256) nt8 = false;   // A/B: bit 256 = default-policy stores, 512 = non-temporal stores, whatever the size
+    if (diag & 512) nt8 = true;
+#endif
+#define NT_LAUNCH8_NT(OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, false, OPS, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
         switch (fl) {
-            case 0: NT_LAUNCH8(0, 3); break;
+            case 0: if (nt8) NT_LAUNCH8_NT(3); else NT_LAUNCH8(0, 3); break;
             case F_LIN: NT_LAUNCH8(F_LIN, 3); break;
             case F_LIN | ECGVIT_EPI_DROPOUT: NT_LAUNCH8(F_LIN | ECGVIT_EPI_DROPOUT, 3); break;
             case F_UP: NT_LAUNCH8(F_UP, 3); break;
@@ -1189,7 +1199,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
         }
     } else if (d->dtype == ECGVIT_BF8_E5M2) {   // input-gradient products: e5m2 gradients x e4m3 transposed weights
         switch (fl) {
-            case 0: NT_LAUNCH8(0, 4); break;
+            case 0: if (nt8) NT_LAUNCH8_NT(4); else NT_LAUNCH8(0, 4); break;
             case F_DH: NT_LAUNCH8(F_DH, 4); break;
             case F_DH | ECGVIT_EPI_QUANT_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT, 4); break;
             case F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT: NT_LAUNCH8(F_DH | ECGVIT_EPI_QUANT_OUT | ECGVIT_EPI_NO_OUT, 4); break;
@@ -1250,6 +1260,7 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     }
 #undef NT_LAUNCH
 #undef NT_LAUNCH8
+#undef NT_LAUNCH8_NT
     ECGVIT_CHECK_LAUNCH();
     if (d->epilogue & ECGVIT_EPI_COLSUM) {
         ecgvit_colsum_reduce_launch((const float *)d->workspace, 2 * tiles_m, d->N, d->colsum_out, s);
