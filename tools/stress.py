@@ -15,7 +15,7 @@ bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = n_aux8 = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'ntlin', 'ntaux8', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8'])
+    kind = rng.choice(['nt', 'nt', 'ntlin', 'ntaux8', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8', 'attnfwd'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -139,6 +139,21 @@ while time.time() < t_end:
             if not torch.equal(C, ref):
                 bad += 1; print('TN8 MISMATCH', M, N, K, afmt, int((C != ref).sum()), flush=True)
         n_tn += 1
+    elif kind == 'attnfwd':   # the streamed forward (round 6: all three workgroup forms) against the one-item kernel, random shapes: bit-identical, repeatable
+        h = rng.choice([1, 2, 3, 5, 12]); N = rng.randrange(1, 513); B = rng.choice([3, 40, 90, 300, 700]) if h < 5 else rng.choice([8, 30, 64])
+        p = rng.choice([0.0, 0.1, 0.3]); d = h * 64
+        qkv = (torch.randn(B * N, 3 * d, device='cuda') * 1.2).to(bf)
+        tl = tools_lib()
+        res = []
+        for v in (0, 1, 1, 2):
+            tl.ecgvit_tools_attn_fwd_variant(v)
+            out = torch.full((B * N, d), float('nan'), device='cuda', dtype=bf); lse = torch.full((B * h * N,), float('nan'), device='cuda')
+            check(tl.ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 91, hip.BF16, stream()), 'f')
+            torch.cuda.synchronize(); res.append((out, lse))
+        tl.ecgvit_tools_attn_fwd_variant(-1)
+        if not all(torch.equal(res[0][0].view(torch.int16), r[0].view(torch.int16)) and torch.equal(res[0][1], r[1]) for r in res[1:]) or not torch.isfinite(res[0][1]).all():
+            bad += 1; print('ATTN FWD streamed != one-item', B, h, N, p, flush=True)
+        n_at += 1
     elif kind == 'attn8':   # the emitting attention kernels against the plain ones: same bf16 results bit for bit, 8-bit copies = casts of them
         h = rng.choice([1, 2, 5, 12]); N = rng.randrange(129, 513); B = rng.choice([3, 40, 90]) if h < 12 else rng.choice([8, 30])
         p = rng.choice([0.0, 0.1]); d = h * 64
