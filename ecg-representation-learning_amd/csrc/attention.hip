@@ -329,8 +329,7 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, 4) void attn_fwd_stream_ker
     constexpr int TPW = WK / 32;          // key tiles per window
     constexpr int GB = WK * 256;          // bytes of one group's K + V images inside a slot
     constexpr int NST = Q8 ? 7 : 5;       // vector-memory operations a wave issues behind its Q request: 4 output stores of 16 B (+ 2 of the 8-bit copy) + the LSE store
-    [[maybe_unused]] unsigned int amax_seen = 0u;
-    if constexpr (Q8) amax_seen = amax_peek(q8_amax);
+    [[maybe_unused]] float qmax = 0.f;      // running |out| maximum of this wave over all its items (8-bit emitting form)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int group = GROUPS == 2 ? wave >> 3 : 0, wq = GROUPS == 2 ? wave & 7 : wave;
     const int nkt = (N + 31) >> 5, nw = (nkt + TPW - 1) / TPW;
@@ -463,7 +462,6 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, 4) void attn_fwd_stream_ker
         l += __shfl_xor(l, 32, 64);
         // output rows: the one-item kernel's 16-B runs (one v_permlane32_swap per dword), as bounds-checked buffer stores
         {
-            [[maybe_unused]] float qmax = 0.f;
             const float inv = inv_keep / l;
             [[maybe_unused]] float q8_inv = 0.f;
             if constexpr (Q8) { const float sc8 = *q8_scale; q8_inv = sc8 > 0.f ? 1.0f / sc8 : 0.f; }
@@ -517,9 +515,12 @@ __global__ __launch_bounds__(MODE == 3 ? 512 : 1024, 4) void attn_fwd_stream_ker
             }
             const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void *)(lse + (int64_t)bh * N), 0, (uint32_t)N * 4u, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m * scale + logf(l)), rl, lh == 0 ? q * 4 : 0x7FFFFFF0, 0, 0);
-            if constexpr (Q8) wave_amax_publish(q8_amax, qmax, amax_seen);
         }
     }
+    // ONE publish per wave and launch, of the running maximum over all its items, against a FRESH look at the slot: a value peeked at the top of a
+    // persistent kernel is stale for every item but the first -- inside the train step the slot is zeroed by the step's scale update, every wave of every
+    // item then sent its atomic (65 k same-address atomics per launch at 256 x 16 x 501: +280 us per layer, found by the whole-line A/B of round 6)
+    if constexpr (Q8) wave_amax_publish(q8_amax, qmax);
 }
 
 // =====================================================================================================
@@ -1401,6 +1402,9 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
 #ifdef ECGVIT_TOOLS
         if (g_tools_attn_fwd_variant == 0) stream_form = false;
         if (g_tools_attn_fwd_variant >= 1) stream_form = (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
+#endif
+#ifdef ECGVIT_AB_NO_STREAM
+        stream_form = false;   // (A/B builds only)
 #endif
         if (stream_form) {
             static bool sattr = false;

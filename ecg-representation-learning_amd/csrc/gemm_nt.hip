@@ -1176,6 +1176,9 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
     if (diag & 256) nt8 = false;   // A/B: bit 256 = default-policy stores, 512 = non-temporal stores, whatever the size
     if (diag & 512) nt8 = true;
 #endif
+#ifdef ECGVIT_AB_NO_NT8
+    nt8 = false;   // (A/B builds only: tools/ab_bench.sh --hip-lib)
+#endif
 #define NT_LAUNCH8_NT(OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, false, OPS, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
         switch (fl) {
