@@ -385,9 +385,10 @@ def test_attention_fwd_streamed_equals_one_item_kernel(B, h, N, p):
     dh = 64
     d = h * dh
     qkv = dev((torch.randn(B * N, 3 * d, generator=g) * 1.3).to(BF16))
-    res = {}
+    res, res8 = {}, {}
+    q8s = torch.full((1,), 0.004, device='cuda')
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):     # 0: one item per workgroup; 1: streamed, 16 waves (two items side by side up to 256 tokens); 2: streamed, 8 waves x 2 workgroups per CU (<= 256 tokens)
             tl.ecgvit_tools_attn_fwd_variant(variant)
             for rep in range(4 if variant else 1):
                 out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
@@ -398,11 +399,24 @@ def test_attention_fwd_streamed_equals_one_item_kernel(B, h, N, p):
                     res[variant] = (out, lse)
                 else:
                     assert torch.equal(out.view(torch.int16), res[variant][0].view(torch.int16)) and torch.equal(lse, res[variant][1]), rep
+            # the 8-bit emitting entry point of the same form: same bf16 results, same e4m3 copy, same amax (the slot starts at zero, as inside a train step)
+            out = torch.full((B * N, d), float('nan'), device='cuda', dtype=BF16)
+            lse = torch.full((B * h * N,), float('nan'), device='cuda')
+            o8 = torch.full((B * N, d), 0x7F, device='cuda', dtype=torch.uint8)
+            am = torch.zeros(1, device='cuda')
+            check(tl.ecgvit_attention_fwd_q8(ptr(qkv), ptr(out), ptr(lse), B, N, h, dh, dh ** -0.5, p, 4321, ptr(o8), ptr(q8s), ptr(am), stream()), 'attn_fwd_q8')
+            torch.cuda.synchronize()
+            res8[variant] = (out, lse, o8, am)
     finally:
         tl.ecgvit_tools_attn_fwd_variant(-1)
     assert torch.isfinite(res[1][0].float()).all() and torch.isfinite(res[1][1]).all()
-    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
-    assert torch.equal(res[0][1], res[1][1])
+    for variant in (1, 2):
+        assert torch.equal(res[0][0].view(torch.int16), res[variant][0].view(torch.int16)), variant
+        assert torch.equal(res[0][1], res[variant][1]), variant
+    for variant in (0, 1, 2):
+        o, l, o8, am = res8[variant]
+        assert torch.equal(o.view(torch.int16), res[0][0].view(torch.int16)) and torch.equal(l, res[0][1]), variant
+        assert torch.equal(o8, res8[0][2]) and float(am) == float(res[0][0].float().abs().max()), variant
 
 
 def test_attention_fwd_product_dispatch_takes_the_streamed_kernel_at_full_occupancy():
