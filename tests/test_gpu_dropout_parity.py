@@ -11,7 +11,9 @@ through the kernel itself with one-hot V), checks that the engine's own activati
   bf16 HIP path (quad 8-bit masks at p' = 26/256, e4m3 saved FFN tensor, 3-term erf): loss <= 2e-2, whole-gradient cosine >= 0.98, every tensor >= 0.95
 
 at the base layer shape (d 768, 12 heads, f 3072, 12 x 5000 samples, patch 20), 2 layers, 10 records = 2 510 / 2 500 token rows (>= 2 048: the large A.B^T kernels,
-the e4m3 saved tensor and the persistent attention backward are on this path), for the supervised step AND the masked pre-train step.
+the e4m3 saved tensor and the persistent attention backward are on this path), for the supervised step AND the masked pre-train step; at the LARGE layer shape
+(d 1024, 16 heads, patch 10 -> 501 / 500 tokens, 16 records: two key windows in the backward, the STREAMED attention forward -- whose mask is observed through the
+streamed kernel itself); and ONE full-depth base model (12 layers, 61 injected mask tensors, 140 gradient tensors, f32 <= 1e-4).
 """
 import pytest
 import torch
@@ -22,13 +24,16 @@ import ecg_representation_learning_amd as E
 
 pytestmark = pytest.mark.gpu
 F32, BF16 = torch.float32, torch.bfloat16
-BASE = dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072)
+SHAPES = {
+    'base': dict(hidden_size=768, num_attention_heads=12, intermediate_size=3072),                     # 251 / 250 tokens
+    'large': dict(hidden_size=1024, num_attention_heads=16, intermediate_size=4096, patch_size=10),    # 501 / 500 tokens: two key windows; 16 records x 16 heads = an item
+}                                                                                                      # per CU: the STREAMED attention forward is on this path
 P_HID, P_EMB = 0.1, 0.1   # reference defaults, models/ecg_vit.py:38-39
 
 
-def _conf(**kw):
+def _conf(name='base', **kw):
     return E.EcgVitConfig(**{**dict(max_signal_length=5000, patch_size=20, num_hidden_layers=2, hidden_dropout_prob=P_HID,
-                                     attention_probs_dropout_prob=P_EMB), **BASE, **kw})
+                                     attention_probs_dropout_prob=P_EMB), **SHAPES[name], **kw})
 
 
 def _cos(a, b):
@@ -47,11 +52,11 @@ def _check_mask_rates(masks, dtype):
             assert abs(float((m != 0).double().mean()) - (1 - pa)) < 3e-3, (k, float((m != 0).double().mean()))
 
 
-@pytest.mark.parametrize('dtype', [F32, BF16])
-def test_supervised_step_dropout_01_vs_cpu_oracle_with_injected_masks(dtype):
+@pytest.mark.parametrize('name,layers,B,dtype', [('base', 2, 10, F32), ('base', 2, 10, BF16), ('large', 2, 16, F32), ('large', 2, 16, BF16), ('base', 12, 10, F32)])
+def test_supervised_step_dropout_01_vs_cpu_oracle_with_injected_masks(name, layers, B, dtype):
+    """(base, 12 layers, f32): the FULL-depth model under dropout 0.1 -- 61 injected mask tensors -- every one of the 140 gradient tensors <= 1e-4"""
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    conf = _conf()
-    B = 10
+    conf = _conf(name, num_hidden_layers=layers)
     torch.manual_seed(5)
     ref = O.OracleEcgVit(config=conf).train()
     m = E.EcgVit(config=conf, compute_dtype=dtype)
@@ -94,13 +99,13 @@ def test_supervised_step_dropout_01_vs_cpu_oracle_with_injected_masks(dtype):
             assert _cos(p.grad, pr[k].grad) > 0.95, (k, _cos(p.grad, pr[k].grad))
 
 
-@pytest.mark.parametrize('dtype', [F32, BF16])
-def test_masked_step_dropout_01_vs_cpu_oracle_with_injected_masks(dtype):
+@pytest.mark.parametrize('name,B,dtype', [('base', 10, F32), ('base', 10, BF16), ('large', 16, BF16)])
+def test_masked_step_dropout_01_vs_cpu_oracle_with_injected_masks(name, B, dtype):
     """the masked pre-train step (250 tokens, no CLS row; embedding dropout on the [B, n, d] token slab) through the FUSED train step
     (`HipTrainStep.step_masked`: the launches `bench.py --objective masked` times), its flat gradient buffer against the oracle's gradients"""
     torch.set_num_threads(min(32, torch.get_num_threads()))
-    conf = _conf()
-    B, n = 10, 250
+    conf = _conf(name)
+    n = 5000 // conf.patch_size
     torch.manual_seed(6)
     ref = O.OracleMaskedEcgVit(O.OracleEcgVit(config=conf)).train()
     mm = E.MaskedEcgVit(E.EcgVit(config=conf, compute_dtype=dtype), mask_ratio=0.5)
