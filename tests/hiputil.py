@@ -135,7 +135,7 @@ def assert_engine_tensors_carry_masks(eng, masks):
     X = a['x0']
     for L, mk in zip(a['layers'], masks['layers']):
         if mk:
-            dropped_implies((L['x1'] == X).cpu(), mk['out'], 'to_out dropout', 5e-2)
+            dropped_implies((L['x1'] == X).cpu(), mk['out'], 'to_out dropout', 0.12)   # (bf16: a kept value below half an ulp of the residual rounds away: 5.5 % at d = 1024)
             dropped_implies((L['hact'].float() == 0).cpu(), mk['ffn'], 'FFN hidden dropout', 1e-3)
-            dropped_implies((L['x2'] == L['x1']).cpu(), mk['down'], 'FFN output dropout', 5e-2)
+            dropped_implies((L['x2'] == L['x1']).cpu(), mk['down'], 'FFN output dropout', 0.12)
         X = L['x2']
