@@ -557,7 +557,7 @@ def main():
                 # what holds the timed path to the reference (tests/, -m gpu): stated next to the number it qualifies
                 'parity': 'f32 HIP path vs CPU oracle <= 1e-4 (loss, logits, every gradient; full-depth base, masked step at this geometry); bf16 path: loss <= 2e-2, '
                           'whole-gradient cosine >= 0.98, every tensor >= 0.95 -- at dropout 0 AND at dropout 0.1 as timed (tests/test_gpu_dropout_parity.py: the masks the HIP '
-                          'kernels drew are exported and injected into the oracle\'s five nn.Dropout sites, supervised and masked step, base layer shape, e4m3 saved tensor and '
+                          'kernels drew are exported and injected into the oracle\'s five nn.Dropout sites, supervised and masked step, base and large layer shapes, one full-depth base model in f32, e4m3 saved tensor and '
                           'quad 8-bit masks on); the oracle\'s transformer arithmetic restates vit-pytorch 0.33.2 (not installable here: parity unpinned)',
             },
             'final_loss': final_loss,
