@@ -331,11 +331,10 @@ class VitEngine:
             self._gemm(GEMM_NN, dY, self.W[name], dX, M, kin, nout, nout, kin, kin, **kw)
 
     def _alloc(self, B, masked=False, m=0):
-        """Activation slabs for a pass over B records.  Every slab's leading dimension is proportional to B, so ONE pool sized for the
-        largest batch seen serves every smaller one through prefix views: a loop that alternates train (B = 512) and eval (B = 64)
-        batches, or ends an epoch on a short batch, re-slices instead of freeing and re-requesting ~40 GB (base) from the allocator on
-        each switch.  The pool is re-made only when a LARGER batch arrives or the objective changes (supervised <-> masked, or another
-        mask count: a different token geometry)."""
+        """Activation slabs for a pass over B records.  Every slab's leading dimension is proportional to B, so ONE pool serves every batch size
+        through prefix views: a loop that alternates train (B = 512) and eval (B = 64) batches, or ends an epoch on a short batch, re-slices instead
+        of freeing and re-requesting ~40 GB (base) from the allocator on each switch.  The pool grows PER SLAB and never shrinks inside a token
+        geometry; it is dropped only when the objective changes (supervised <-> masked, or another mask count)."""
         key = (B, masked, m, self._aux8(B * (self.n if masked else self.N)))
         if self._alloc_key == key and self.act is not None:
             return
