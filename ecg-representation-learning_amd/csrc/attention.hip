@@ -761,7 +761,7 @@ __global__ __launch_bounds__(512) void attn_bwd_pers_kernel(const bf16_t *__rest
     constexpr int SF = (Q8 & 1) ? 16 : 8;    // dK / dV stores of one item's flush
     [[maybe_unused]] float q8_inv = 0.f, qmax = 0.f;
     if constexpr (Q8 != 0) { const float sc = *q8_scale; q8_inv = sc > 0.f ? 1.0f / sc : 0.f; }
-    constexpr int NKT = 8, NK = 256, NQ = 512, IMG = 32768, DSB = 16384, SLAB = 12288;
+    constexpr int NQ = 512, IMG = 32768, DSB = 16384, SLAB = 12288;
     __shared__ __attribute__((aligned(1024))) char smem[2 * IMG + 4 * SLAB + 2 * DSB + 2 * NQ * 4 + 2 * 32 * 4];
     char *const Kimg0 = smem, *const slab0 = smem + 2 * IMG, *const dSimg = slab0 + 4 * SLAB;
     float *const lse_s = reinterpret_cast<float *>(dSimg + 2 * DSB), *const delta_s = lse_s + 2 * NQ;
@@ -1393,9 +1393,11 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return ECGVIT_ELAUNCH;
             n_cu = v;
         }
-        int mode = N > 256 ? 1 : 2;
+        // (MODE 2 / 3 -- the two forms for up to 256 tokens, both slower than the one-item kernel there -- exist in the TOOLS build only: tools/attn_fwd_ab.py,
+        // tests/test_gpu_ops.py hold them bit for bit against the one-item kernel)
+        int mode = 1;
 #ifdef ECGVIT_TOOLS
-        if (g_tools_attn_fwd_variant == 2 && N <= 256) mode = 3;
+        if (N <= 256) mode = g_tools_attn_fwd_variant == 2 ? 3 : 2;
 #endif
         const int groups = mode == 2 ? 2 : 1, nsuper = (B * h + groups - 1) / groups;
         bool stream_form = N > 256 && nsuper >= n_cu && (int64_t)N * 3 * h * 64 * 2 < (1ll << 31);
@@ -1411,8 +1413,10 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
             if (!sattr) {
 #define SATTR(DR, Q, G) if (hipFuncSetAttribute((const void *)attn_fwd_stream_kernel<DR, Q, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) return ECGVIT_ELAUNCH
                 SATTR(true, false, 1); SATTR(false, false, 1); SATTR(true, true, 1); SATTR(false, true, 1);
+#ifdef ECGVIT_TOOLS
                 SATTR(true, false, 2); SATTR(false, false, 2); SATTR(true, true, 2); SATTR(false, true, 2);
                 SATTR(true, false, 3); SATTR(false, false, 3); SATTR(true, true, 3); SATTR(false, true, 3);
+#endif
 #undef SATTR
                 sattr = true;
             }
@@ -1420,7 +1424,11 @@ static int attention_fwd_launch(const void *qkv, void *out, float *lse, int B, i
             const dim3 sg((unsigned)(nsuper < slots ? nsuper : slots)), sb(mode == 3 ? 512 : 1024);
             const size_t slds = mode == 3 ? 64 * 1024 : 128 * 1024;
 #define SFWD(DR, Q, G) hipLaunchKernelGGL((attn_fwd_stream_kernel<DR, Q, G>), sg, sb, slds, as_stream(stream), (const bf16_t *)qkv, (bf16_t *)out, lse, N, h, scale, seed, th, ik, B * h, (uint8_t *)out8, q8_scale, q8_amax)
+#ifdef ECGVIT_TOOLS
 #define SFWD2(DR, Q) do { if (mode == 1) SFWD(DR, Q, 1); else if (mode == 2) SFWD(DR, Q, 2); else SFWD(DR, Q, 3); } while (0)
+#else
+#define SFWD2(DR, Q) SFWD(DR, Q, 1)
+#endif
             if (out8) { if (th) SFWD2(true, true); else SFWD2(false, true); }
             else { if (th) SFWD2(true, false); else SFWD2(false, false); }
 #undef SFWD2
