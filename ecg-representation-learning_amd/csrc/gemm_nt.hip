@@ -1179,6 +1179,9 @@ int ecgvit_gemm_nt_launch(const ecgvit_gemm_desc *d, hipStream_t s, int raster_g
 #ifdef ECGVIT_AB_NO_NT8
     nt8 = false;   // (A/B builds only: tools/ab_bench.sh --hip-lib)
 #endif
+#ifdef ECGVIT_AB_NT8_BIG_ONLY
+    nt8 = (int64_t)d->M * d->N * 2 > (320ll << 20);
+#endif
 #define NT_LAUNCH8_NT(OPS) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 0, false, OPS, 2>), grid, block, 0, s, *d, e, tiles_m, tiles_n, G, ntile, 0)
     if (d->dtype == ECGVIT_FP8_E4M3) {          // forward products: e4m3 activations x e4m3 weights
         switch (fl) {
