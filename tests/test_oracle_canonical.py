@@ -92,3 +92,52 @@ def test_injected_dropout_replays_torchs_own_realisation():
     O.inject_dropout(ref.vit, None)
     with torch.no_grad():
         assert not torch.equal(ref(sample_values=x).logits, o1.logits)                       # injection removed: eval mode is dropout-free again
+
+
+def test_oracle_trunk_matches_huggingface_vit_layers():
+    """a SECOND independent implementation of the same published block: HuggingFace `transformers` `ViTLayer` (pre-LN: layernorm_before -> self-attention ->
+    residual -> layernorm_after -> GELU MLP -> residual; separate bias-free q / k / v projections = the three row blocks of vit-pytorch's packed `to_qkv`).
+    Same weights in, same activations and input gradients out -- to 1e-6 in float64 (HF's eager attention takes its softmax in float32).  Like the
+    nn.TransformerEncoderLayer check above this does NOT pin the oracle to vit-pytorch's code (the package is not installable here: parity unpinned); it shows
+    once more that the restated arithmetic is the canonical pre-LN ViT block."""
+    import pytest
+    from oracle import vit_oracle as O
+    try:
+        from transformers import ViTConfig
+        from transformers.models.vit.modeling_vit import ViTLayer
+    except Exception as e:   # pragma: no cover
+        pytest.skip(f'transformers ViT not importable: {e}')
+    torch.manual_seed(3)
+    dim, depth, heads, dh, mlp = 64, 3, 4, 16, 160
+    cfg = ViTConfig(hidden_size=dim, num_hidden_layers=depth, num_attention_heads=heads, intermediate_size=mlp, hidden_act='gelu', hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0, layer_norm_eps=1e-5, qkv_bias=False)
+    cfg._attn_implementation = 'eager'
+    layers = torch.nn.ModuleList([ViTLayer(cfg) for _ in range(depth)]).double()
+    if not hasattr(layers[0].attention, 'q_proj') or not hasattr(layers[0], 'mlp'):
+        pytest.skip('this transformers release lays ViTLayer out differently (written against 5.15: attention.{q,k,v,o}_proj, mlp.fc1 / fc2)')
+    trunk = O._Transformer(dim, depth, heads, dh, mlp, 0.0).double()
+    with torch.no_grad():
+        for (attn, ff), lay in zip(trunk.layers, layers):
+            for p in list(attn.parameters()) + list(ff.parameters()):
+                p.copy_(torch.randn_like(p) * 0.2)
+            W, sa = attn.fn.to_qkv.weight, lay.attention
+            sa.q_proj.weight.copy_(W[:dim]); sa.k_proj.weight.copy_(W[dim:2 * dim]); sa.v_proj.weight.copy_(W[2 * dim:])
+            sa.o_proj.weight.copy_(attn.fn.to_out[0].weight); sa.o_proj.bias.copy_(attn.fn.to_out[0].bias)
+            lay.layernorm_before.weight.copy_(attn.norm.weight); lay.layernorm_before.bias.copy_(attn.norm.bias)
+            lay.layernorm_after.weight.copy_(ff.norm.weight); lay.layernorm_after.bias.copy_(ff.norm.bias)
+            lay.mlp.fc1.weight.copy_(ff.fn.net[0].weight); lay.mlp.fc1.bias.copy_(ff.fn.net[0].bias)
+            lay.mlp.fc2.weight.copy_(ff.fn.net[3].weight); lay.mlp.fc2.bias.copy_(ff.fn.net[3].bias)
+    x = torch.randn(3, 37, dim, dtype=torch.float64)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    trunk.train(); layers.train()
+    ya, h = trunk(xa), xb
+    for lay in layers:
+        out = lay(h)
+        h = out[0] if isinstance(out, tuple) else out
+    assert float((ya - h).detach().abs().max()) < 1e-6
+    g = torch.randn_like(ya)
+    ya.backward(g); h.backward(g)
+    assert float((xa.grad - xb.grad).abs().max()) < 1e-6
+    for (attn, ff), lay in zip(trunk.layers, layers):
+        assert float((attn.fn.to_qkv.weight.grad[:dim] - lay.attention.q_proj.weight.grad).abs().max()) < 1e-5
+        assert float((ff.fn.net[0].weight.grad - lay.mlp.fc1.weight.grad).abs().max()) < 1e-5
