@@ -85,15 +85,19 @@ def test_supervised_step_dropout_01_vs_cpu_oracle_with_injected_masks(name, laye
     lerr = abs(float(out.loss.detach()) - float(o_ref.loss.detach())) / float(o_ref.loss.detach())
     pr = dict(ref.named_parameters())
     if dtype == F32:
+        worst = max(rel_err(p.grad, pr[k].grad) for k, p in m.named_parameters())
+        print(f'[{name} x {layers} f32, dropout 0.1] loss rel {lerr:.2e}, logits max {max_err(out.logits, o_ref.logits):.2e}, worst gradient tensor rel {worst:.2e}')
         assert lerr < 1e-4, lerr
         assert max_err(out.logits, o_ref.logits) < 1e-4
         for k, p in m.named_parameters():
             assert rel_err(p.grad, pr[k].grad) < 1e-4, (k, rel_err(p.grad, pr[k].grad))
     else:
-        assert lerr < 2e-2, lerr
-        assert max_err(out.logits, o_ref.logits) < 0.15
         g16 = torch.cat([p.grad.flatten() for _, p in m.named_parameters()])
         gref = torch.cat([pr[k].grad.flatten() for k, _ in m.named_parameters()])
+        worst = min(_cos(p.grad, pr[k].grad) for k, p in m.named_parameters())
+        print(f'[{name} x {layers} bf16, dropout 0.1] loss rel {lerr:.2e}, logits max {max_err(out.logits, o_ref.logits):.2e}, gradient cosine {_cos(g16, gref):.5f}, worst tensor {worst:.5f}')
+        assert lerr < 2e-2, lerr
+        assert max_err(out.logits, o_ref.logits) < 0.15
         assert _cos(g16, gref) > 0.98, _cos(g16, gref)
         for k, p in m.named_parameters():
             assert _cos(p.grad, pr[k].grad) > 0.95, (k, _cos(p.grad, pr[k].grad))
