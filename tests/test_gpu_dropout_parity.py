@@ -96,11 +96,13 @@ def test_supervised_step_dropout_01_vs_cpu_oracle_with_injected_masks(name, laye
         gref = torch.cat([pr[k].grad.flatten() for k, _ in m.named_parameters()])
         worst = min(_cos(p.grad, pr[k].grad) for k, p in m.named_parameters())
         print(f'[{name} x {layers} bf16, dropout 0.1] loss rel {lerr:.2e}, logits max {max_err(out.logits, o_ref.logits):.2e}, gradient cosine {_cos(g16, gref):.5f}, worst tensor {worst:.5f}')
-        assert lerr < 2e-2, lerr
-        assert max_err(out.logits, o_ref.logits) < 0.15
-        assert _cos(g16, gref) > 0.98, _cos(g16, gref)
+        # (observed on MI355X: loss 1.5e-5 / 2.2e-5, logits 6e-3 / 8e-3, whole-gradient cosine 0.99999, worst tensor 0.99993 -- the bounds asked for are 2e-2,
+        # 0.98 and 0.95; held ten times tighter here so that a mask or saved-tensor mismatch of a few elements in a thousand fails)
+        assert lerr < 2e-3, lerr
+        assert max_err(out.logits, o_ref.logits) < 0.05
+        assert _cos(g16, gref) > 0.999, _cos(g16, gref)
         for k, p in m.named_parameters():
-            assert _cos(p.grad, pr[k].grad) > 0.95, (k, _cos(p.grad, pr[k].grad))
+            assert _cos(p.grad, pr[k].grad) > 0.99, (k, _cos(p.grad, pr[k].grad))
 
 
 @pytest.mark.parametrize('name,B,dtype', [('base', 10, F32), ('base', 10, BF16), ('large', 16, BF16)])
