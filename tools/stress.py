@@ -10,12 +10,13 @@ from toolslib import tools_lib
 import bench as _bench  # noqa: E402
 print('kernel_source_sha16:', _bench.kernel_source_hash(), '(sources of the library build measured: tools/check_profiles.py holds committed tables to the round\'s bench line)', flush=True)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+only = sys.argv[2] if len(sys.argv) > 2 else None   # e.g. `python tools/stress.py 300 attnfwd`: one kind of case only
 rng = random.Random(1234)
 bf = torch.bfloat16
 t_end = time.time() + budget
 n_nt = n_tn = n_at = n_aux8 = bad = 0
 while time.time() < t_end:
-    kind = rng.choice(['nt', 'nt', 'ntlin', 'ntaux8', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8', 'attnfwd'])
+    kind = only or rng.choice(['nt', 'nt', 'ntlin', 'ntaux8', 'nt8', 'nt8emit', 'tn', 'tn', 'tn8', 'attn', 'attn8', 'attnfwd'])
     if kind == 'nt':
         M = rng.choice([2048, 4133, 20000, 66000, 128512]) + rng.randrange(0, 256)
         N = rng.choice([128, 240, 256, 520, 768, 776, 2304, 3072])
@@ -150,9 +151,17 @@ while time.time() < t_end:
             out = torch.full((B * N, d), float('nan'), device='cuda', dtype=bf); lse = torch.full((B * h * N,), float('nan'), device='cuda')
             check(tl.ecgvit_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 91, hip.BF16, stream()), 'f')
             torch.cuda.synchronize(); res.append((out, lse))
+        sc = torch.full((1,), 0.004, device='cuda'); res8 = []
+        for v in (0, 1, 2):          # the 8-bit emitting entry point of each form, the amax slot zeroed as inside a train step
+            tl.ecgvit_tools_attn_fwd_variant(v)
+            out = torch.full((B * N, d), float('nan'), device='cuda', dtype=bf); lse = torch.full((B * h * N,), float('nan'), device='cuda')
+            o8 = torch.full((B * N, d), 0x7F, device='cuda', dtype=torch.uint8); am = torch.zeros(1, device='cuda')
+            check(tl.ecgvit_attention_fwd_q8(ptr(qkv), ptr(out), ptr(lse), B, N, h, 64, 0.125, p, 91, ptr(o8), ptr(sc), ptr(am), stream()), 'f8')
+            torch.cuda.synchronize(); res8.append((out, lse, o8, float(am)))
         tl.ecgvit_tools_attn_fwd_variant(-1)
-        if not all(torch.equal(res[0][0].view(torch.int16), r[0].view(torch.int16)) and torch.equal(res[0][1], r[1]) for r in res[1:]) or not torch.isfinite(res[0][1]).all():
-            bad += 1; print('ATTN FWD streamed != one-item', B, h, N, p, flush=True)
+        ok8 = all(torch.equal(res[0][0].view(torch.int16), r[0].view(torch.int16)) and torch.equal(res[0][1], r[1]) and torch.equal(res8[0][2], r[2]) and r[3] == res8[0][3] for r in res8)
+        if not all(torch.equal(res[0][0].view(torch.int16), r[0].view(torch.int16)) and torch.equal(res[0][1], r[1]) for r in res[1:]) or not torch.isfinite(res[0][1]).all() or not ok8:
+            bad += 1; print('ATTN FWD streamed != one-item', B, h, N, p, ok8, flush=True)
         n_at += 1
     elif kind == 'attn8':   # the emitting attention kernels against the plain ones: same bf16 results bit for bit, 8-bit copies = casts of them
         h = rng.choice([1, 2, 5, 12]); N = rng.randrange(129, 513); B = rng.choice([3, 40, 90]) if h < 12 else rng.choice([8, 30])
